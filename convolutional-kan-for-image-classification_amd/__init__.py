@@ -1,0 +1,12 @@
+"""convkan_amd: MI355X-native conv-KAN layers (B-spline, FastKAN/RBF, Chebyshev) behind the
+constructor / factory API of GadGadGad/Convolutional-KAN-for-Image-Classification.
+
+Import as ``convkan_amd`` (the repo-root shim maps that name onto this directory, whose
+on-disk name ``convolutional-kan-for-image-classification_amd`` is not a Python identifier).
+"""
+from . import _lib, ops                                                   # noqa: F401
+from .layers import (CONV_KAN_FACTORY, KANConv2DLayer, KANConvNDLayer, FastKANConv2DLayer, FastKANConvNDLayer,   # noqa: F401
+                     ChebyKANConv2DLayer, ChebyKANConvNDLayer, RadialBasisFunction, kan_conv, fastkan_conv, chebykan_conv, conv)
+from .build import build_library                                          # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,83 @@
+"""ctypes binding of libkanconv.so (C ABI declared in include/kanconv.h).
+
+The library is built in-tree by ``build.py`` (hipcc --offload-arch=gfx950).  There is no
+fallback: if the shared object is missing or a call fails, the op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkanconv.so")
+
+KAN_MAX_PLANES = 16
+KAN_MAX_TABLE = 32
+BASIS_BSPLINE, BASIS_RBF, BASIS_CHEBY = 0, 1, 2
+ACT_NONE, ACT_IDENTITY, ACT_GELU, ACT_SILU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_TANH = -1, 0, 1, 2, 3, 4, 5, 6
+
+
+class KanGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "O", "Ho", "Wo", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw")] + \
+               [("x_bstride", C.c_longlong), ("y_bstride", C.c_longlong)]
+
+
+class KanBasis(C.Structure):
+    _fields_ = [("kind", C.c_int), ("n_basis", C.c_int), ("order", C.c_int), ("act", C.c_int),
+                ("p0", C.c_float), ("p1", C.c_float), ("table", C.c_float * KAN_MAX_TABLE)]
+
+
+class KanPlan(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("P", "K", "Kpad", "Opad", "fwd_splits", "bwd_data_splits", "bwd_weight_splits")] + \
+               [(n, C.c_longlong) for n in ("packed_weight_bytes", "fwd_slab_elems", "bwd_data_slab_elems", "bwd_weight_slab_elems")]
+
+
+# every symbol include/kanconv.h declares, with its argument types
+_P, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+_GP, _BP = C.POINTER(KanGeom), C.POINTER(KanBasis)
+SIGNATURES = {
+    "kan_version": (C.c_char_p, []),
+    "kan_last_error": (C.c_char_p, []),
+    "kan_plan": (_I, [_GP, _BP, C.POINTER(KanPlan)]),
+    "kan_pack_weights": (_I, [_P, _P, _P, _GP, _BP, _P]),
+    "kan_conv_fwd": (_I, [_P, _P, _P, _P, _GP, _BP, _P]),
+    "kan_conv_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _GP, _BP, _P]),
+    "kan_conv_bwd_weight": (_I, [_P, _P, _P, _P, _GP, _BP, _P]),
+    "kan_unpack_wgrad": (_I, [_P, _P, _P, _GP, _BP, _P]),
+    "kan_slab_reduce": (_I, [_P, _I, _LL, _P, _I, _I, _I, _LL, _P]),
+    "kan_instnorm_prelu_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _F, _P]),
+    "kan_instnorm_prelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class KanConvError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libkanconv.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KanConvError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU / eager fallback for this path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().kan_last_error().decode(errors="replace")
+        raise KanConvError(f"{what} failed (rc={rc}): {msg}")
+
+
+def version() -> str:
+    return load().kan_version().decode()

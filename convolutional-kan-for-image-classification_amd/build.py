@@ -1,0 +1,32 @@
+"""In-tree build of libkanconv.so with hipcc for gfx950 (no JIT cache: the .so travels with the repo)."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+SOURCES = [os.path.join(_HERE, "csrc", "kanconv.hip")]
+HEADERS = [os.path.join(_HERE, "csrc", "kan_device.h"), os.path.join(_ROOT, "include", "kanconv.h")]
+OUTPUT = os.path.join(_HERE, "libkanconv.so")
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUTPUT):
+        return True
+    t = os.path.getmtime(OUTPUT)
+    return any(os.path.getmtime(f) > t for f in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/kanconv.hip -> libkanconv.so (skipped when up to date).  Returns the .so path."""
+    if not force and not _stale():
+        return OUTPUT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libkanconv.so")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", os.path.join(_ROOT, "include"),
+           "-I", os.path.join(_HERE, "csrc"), "-o", OUTPUT] + SOURCES
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return OUTPUT

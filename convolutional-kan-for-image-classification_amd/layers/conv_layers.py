@@ -1,0 +1,283 @@
+"""Drop-in conv-KAN layers: same constructor signatures, attribute names, parameter order and
+state_dict keys as the reference classes, with forward/backward on the libkanconv HIP kernels.
+
+  reference class                                   this file
+  layers/kan_layers.py:116-258  KANConvNDLayer       KANConvNDLayer
+  layers/kan_layers.py:274-284  KANConv2DLayer       KANConv2DLayer
+  layers/fast_kan_layers.py:34-120 / :137-148        FastKANConvNDLayer / FastKANConv2DLayer
+  layers/cheby_kan_layers.py:39-111 / :124-131       ChebyKANConvNDLayer / ChebyKANConv2DLayer
+  utils/utils.py:19-33          RadialBasisFunction  RadialBasisFunction
+
+The ``nn.Conv2d`` children are weight holders only (their forward is never called): keeping them
+preserves ``state_dict`` keys (``base_conv.0.weight`` ...), lets ``load_state_dict`` move weights
+between this package and the reference in both directions, and keeps callers that walk
+``.modules()`` for ``nn.Conv2d`` (models/kan_alexnet.py:236-241) working.
+
+Only the 2-D layers are implemented (1-D / 3-D shims are SURVEY.md section 8(f) "next").
+"""
+from __future__ import annotations
+
+from inspect import signature
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib as L
+from .. import ops
+
+
+def _pair(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 2:
+            raise ValueError(f"expected an int or a pair, got {v!r}")
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+_ACT_CODES = {nn.Identity: L.ACT_IDENTITY, nn.SiLU: L.ACT_SILU, nn.ReLU: L.ACT_RELU, nn.Tanh: L.ACT_TANH, nn.Sigmoid: L.ACT_SIGMOID}
+
+
+def _act_code(module: nn.Module) -> int:
+    """Map the instantiated ``base_activation`` module to a kernel activation id."""
+    if type(module) is nn.GELU:
+        return L.ACT_GELU_TANH if getattr(module, "approximate", "none") == "tanh" else L.ACT_GELU
+    code = _ACT_CODES.get(type(module))
+    if code is None:
+        raise NotImplementedError(
+            f"base_activation {type(module).__name__} has no HIP functor yet (supported: Identity/None, GELU, SiLU, ReLU, Tanh, Sigmoid)")
+    return code
+
+
+def _dropout2d(p: float):
+    return nn.Dropout2d(p=p) if p > 0 else None
+
+
+def _check_groups(groups, input_dim, output_dim):
+    # kan_layers.py:148-153 (same messages in the sibling classes)
+    if groups <= 0:
+        raise ValueError('groups must be a positive integer')
+    if input_dim % groups != 0:
+        raise ValueError('input_dim must be divisible by groups')
+    if output_dim % groups != 0:
+        raise ValueError('output_dim must be divisible by groups')
+
+
+def _filter_norm_kwargs(norm_class, norm_kwargs):
+    valid = signature(norm_class).parameters          # kan_layers.py:178-179
+    return {k: v for k, v in norm_kwargs.items() if k in valid}
+
+
+def _fusable_instnorm(mods) -> bool:
+    """True when every per-group norm is a plain InstanceNorm2d (instance statistics in train and eval)."""
+    return all(type(m) is nn.InstanceNorm2d and not m.track_running_stats for m in mods)
+
+
+def _need_conv2d(conv_class, ndim):
+    if conv_class is not nn.Conv2d or ndim != 2:
+        raise NotImplementedError("only the 2-D layers are implemented on the HIP path (1-D/3-D: SURVEY.md 8(f))")
+
+
+class _HipLayer(nn.Module):
+    def _spec(self, **kw) -> ops.ConvSpec:
+        return ops.ConvSpec(kernel=_pair(self.kernel_size), stride=_pair(self.stride), padding=_pair(self.padding),
+                            dilation=_pair(self.dilation), groups=self.groups, **kw)
+
+    @staticmethod
+    def _norm_affine(mods):
+        if mods[0].affine:
+            return [m.weight for m in mods], [m.bias for m in mods]
+        return None, None
+
+
+# =========================================================================================== B-spline
+class KANConvNDLayer(_HipLayer):
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, spline_order, kernel_size,
+                 groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, grid_size=5, base_activation=nn.GELU, grid_range=[-1, 1], dropout=0.0,
+                 **norm_kwargs):
+        super().__init__()
+        _need_conv2d(conv_class, ndim)
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self.spline_order, self.kernel_size = spline_order, kernel_size
+        self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
+        self.grid_size = grid_size
+        self.base_activation = base_activation() if base_activation is not None else nn.Identity()
+        self.grid_range = grid_range
+        self.norm_kwargs = norm_kwargs
+        self.dropout = _dropout2d(dropout)
+        _check_groups(groups, input_dim, output_dim)
+        self.input_dim_group, self.output_dim_group = input_dim // groups, output_dim // groups
+
+        cg, og = self.input_dim_group, self.output_dim_group
+        self.base_conv = nn.ModuleList([conv_class(cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                        for _ in range(groups)])
+        self.spline_conv = nn.ModuleList([conv_class((grid_size + spline_order) * cg, og, kernel_size, stride, padding, dilation,
+                                                     groups=1, bias=False) for _ in range(groups)])
+        self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
+        self.prelus = nn.ModuleList([nn.PReLU() for _ in range(groups)])
+
+        h = (self.grid_range[1] - self.grid_range[0]) / grid_size
+        # plain attribute, not a buffer: absent from state_dict exactly as in kan_layers.py:184-190
+        self.grid = torch.linspace(self.grid_range[0] - h * spline_order, self.grid_range[1] + h * spline_order,
+                                   grid_size + 2 * spline_order + 1, dtype=torch.float32)
+        for conv in self.base_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        for conv in self.spline_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        self._act_code = _act_code(self.base_activation)
+
+    def conv_spec(self) -> ops.ConvSpec:
+        return self._spec(kind=L.BASIS_BSPLINE, n_basis=self.grid_size + self.spline_order, order=self.spline_order,
+                          act=self._act_code, p0=0.0, p1=0.0, table=tuple(float(v) for v in self.grid.tolist()))
+
+    def forward(self, x):
+        spec = self.conv_spec()
+        wb = [m.weight for m in self.base_conv]
+        ws = [m.weight for m in self.spline_conv]
+        prelus = [m.weight for m in self.prelus]
+        if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
+            gam, bet = self._norm_affine(self.layer_norm)
+            y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
+        else:
+            # other norm classes (e.g. BatchNorm2d): HIP conv stage, then the caller's own norm module
+            z = ops.kan_conv(spec, x, None, wb, ws)
+            og = self.output_dim_group
+            y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
+        if self.dropout is not None:
+            y = self.dropout(y)
+        return y
+
+
+class KANConv2DLayer(KANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, spline_order=3, groups=1, padding=0, stride=1, dilation=1,
+                 grid_size=5, base_activation=nn.GELU, grid_range=[-1, 1], dropout=0.0, norm_layer=nn.InstanceNorm2d,
+                 **norm_kwargs):
+        super().__init__(nn.Conv2d, norm_layer, input_dim, output_dim, spline_order, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2,
+                         grid_size=grid_size, base_activation=base_activation, grid_range=grid_range, dropout=dropout,
+                         **norm_kwargs)
+
+
+# =========================================================================================== FastKAN
+class RadialBasisFunction(nn.Module):
+    """Parameter holder mirroring utils/utils.py:19-33 (state_dict key ``rbf.grid``)."""
+
+    def __init__(self, grid_min: float = -2., grid_max: float = 2., num_grids: int = 8, denominator: Optional[float] = None):
+        super().__init__()
+        self.grid = nn.Parameter(torch.linspace(grid_min, grid_max, num_grids), requires_grad=False)
+        self.denominator = denominator or (grid_max - grid_min) / (num_grids - 1)
+
+
+class FastKANConvNDLayer(_HipLayer):
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size,
+                 groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, grid_size=8, base_activation=nn.SiLU, grid_range=[-2, 2], dropout=0.0, **norm_kwargs):
+        super().__init__()
+        _need_conv2d(conv_class, ndim)
+        self.input_dim, self.output_dim, self.kernel_size = input_dim, output_dim, kernel_size
+        self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
+        self.grid_size = grid_size
+        self.base_activation = base_activation() if base_activation is not None else nn.Identity()
+        self.grid_range = grid_range
+        self.norm_kwargs = norm_kwargs
+        _check_groups(groups, input_dim, output_dim)
+        cg, og = input_dim // groups, output_dim // groups
+        self.base_conv = nn.ModuleList([conv_class(cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                        for _ in range(groups)])
+        self.spline_conv = nn.ModuleList([conv_class(grid_size * cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                          for _ in range(groups)])
+        self.layer_norm = nn.ModuleList([norm_class(cg, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
+        self.rbf = RadialBasisFunction(grid_range[0], grid_range[1], grid_size)
+        self.dropout = _dropout2d(dropout)
+        for conv in self.base_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        for conv in self.spline_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        self._act_code = _act_code(self.base_activation)
+        self._centres = tuple(float(v) for v in self.rbf.grid.detach().tolist())
+
+    def conv_spec(self) -> ops.ConvSpec:
+        return self._spec(kind=L.BASIS_RBF, n_basis=self.grid_size, order=0, act=self._act_code,
+                          p0=float(self.rbf.denominator), p1=0.0, table=self._centres)
+
+    def forward(self, x):
+        # fast_kan_layers.py:100-111: the base branch sees raw x; the RBFs see norm(dropout(x))
+        xs = self.dropout(x) if self.dropout is not None else x
+        cg = self.input_dim // self.groups
+        if _fusable_instnorm(self.layer_norm):
+            if self.layer_norm[0].affine:
+                gam = torch.cat([m.weight for m in self.layer_norm])
+                bet = torch.cat([m.bias for m in self.layer_norm])
+            else:
+                gam = bet = None
+            xn = ops.instance_norm(xs, gam, bet, eps=self.layer_norm[0].eps)
+        else:
+            xn = torch.cat([self.layer_norm[g](xs[:, g * cg:(g + 1) * cg]) for g in range(self.groups)], dim=1)
+        return ops.kan_conv(self.conv_spec(), x, xn, [m.weight for m in self.base_conv], [m.weight for m in self.spline_conv])
+
+
+class FastKANConv2DLayer(FastKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, groups=1, padding=0, stride=1, dilation=1,
+                 grid_size=8, base_activation=nn.SiLU, grid_range=[-2, 2], dropout=0.0,
+                 norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(nn.Conv2d, norm_layer, input_dim, output_dim, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2,
+                         grid_size=grid_size, base_activation=base_activation, grid_range=grid_range,
+                         dropout=dropout, **norm_kwargs)
+
+
+# =========================================================================================== ChebyKAN
+class ChebyKANConvNDLayer(_HipLayer):
+    def __init__(self, conv_class, norm_layer, input_dim, output_dim, degree, kernel_size,
+                 groups=1, padding=0, stride=1, dilation=1, ndim: int = 2, dropout=0.0, **norm_kwargs):
+        super().__init__()
+        _need_conv2d(conv_class, ndim)
+        self.input_dim, self.output_dim, self.degree, self.kernel_size = input_dim, output_dim, degree, kernel_size
+        self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
+        self.norm_kwargs = norm_kwargs
+        self.epsilon = 1e-7
+        self.dropout = _dropout2d(dropout)
+        _check_groups(groups, input_dim, output_dim)
+        og = output_dim // groups
+        self.layer_norm = nn.ModuleList([norm_layer(og, **_filter_norm_kwargs(norm_layer, norm_kwargs)) for _ in range(groups)])
+        self.poly_conv = nn.ModuleList([conv_class((degree + 1) * input_dim // groups, og, kernel_size, stride, padding, dilation,
+                                                   groups=1, bias=False) for _ in range(groups)])
+        self.register_buffer("arange", torch.arange(0, degree + 1, 1).view(1, 1, -1, 1, 1))
+        for conv in self.poly_conv:
+            # cheby_kan_layers.py:88-90 (normal_ first, then overwritten; `**` requires an int kernel_size, as there)
+            nn.init.normal_(conv.weight, mean=0.0, std=1 / (input_dim * (degree + 1) * kernel_size ** ndim))
+            nn.init.kaiming_normal_(conv.weight, mode='fan_in', nonlinearity='relu')
+
+    def conv_spec(self) -> ops.ConvSpec:
+        lo = float(np.float32(-1 + self.epsilon))       # torch.clamp casts its Python-float bounds to fp32
+        hi = float(np.float32(1 - self.epsilon))
+        return self._spec(kind=L.BASIS_CHEBY, n_basis=self.degree + 1, order=0, act=L.ACT_NONE, p0=lo, p1=hi, table=())
+
+    def forward(self, x):
+        spec = self.conv_spec()
+        wp = [m.weight for m in self.poly_conv]
+        if _fusable_instnorm(self.layer_norm):
+            gam, bet = self._norm_affine(self.layer_norm)
+            y = ops.kan_conv_in_prelu(spec, x, [], wp, gam, bet, None, eps=self.layer_norm[0].eps)
+        else:
+            z = ops.kan_conv(spec, x, None, [], wp)
+            og = self.output_dim // self.groups
+            y = torch.cat([self.layer_norm[g](z[:, g * og:(g + 1) * og]) for g in range(self.groups)], dim=1)
+        if self.dropout is not None:
+            y = self.dropout(y)
+        return y
+
+
+class ChebyKANConv2DLayer(ChebyKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree=3, groups=1, padding=0, stride=1, dilation=1,
+                 dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(nn.Conv2d, norm_layer, input_dim, output_dim, degree, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2, dropout=dropout, **norm_kwargs)
+
+
+__all__ = ["KANConvNDLayer", "KANConv2DLayer", "FastKANConvNDLayer", "FastKANConv2DLayer",
+           "ChebyKANConvNDLayer", "ChebyKANConv2DLayer", "RadialBasisFunction"]
+_ = F

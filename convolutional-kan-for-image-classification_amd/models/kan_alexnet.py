@@ -1,0 +1,74 @@
+"""KAN-AlexNet caller (counterpart of the reference's models/kan_alexnet.py:10-313), plain FC head only."""
+from functools import partial
+from inspect import signature
+from typing import Any, Callable, List, Optional
+
+import torch
+import torch.nn as nn
+
+from ..layers.kan_conv import CONV_KAN_FACTORY
+
+
+class AlexNetKAN(nn.Module):
+    def __init__(self, num_classes: int = 1000, dropout: float = 0.5, input_channels: int = 3, arch: str = "default",
+                 kan_conv: str = "KAN", classifier_type: str = "Linear", groups: int = 1, spline_order: int = 3, grid_size: int = 5,
+                 base_activation: Optional[Callable[..., nn.Module]] = nn.SiLU, grid_range: List = [-1, 1],
+                 degree: Optional[int] = 3, l1_decay: float = 0.0, affine: bool = True,
+                 kan_norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, classifier_dropout: Optional[float] = None,
+                 conv_dropout: float = 0.0, **kwargs: Any) -> None:
+        super().__init__()
+        if classifier_type not in ("Linear", "AlexNet"):
+            raise NotImplementedError("KAN MLP heads are outside the accelerated path (classifier_type 'Linear' or 'AlexNet')")
+        if kan_conv not in CONV_KAN_FACTORY:
+            raise ValueError(f"kan_conv={kan_conv!r} is not on the accelerated path: {list(CONV_KAN_FACTORY)}")
+        make = CONV_KAN_FACTORY[kan_conv]
+        # kan_alexnet.py:54-69: these go in unfiltered, so e.g. `affine` reaches the layer's **norm_kwargs
+        args = dict(spline_order=spline_order, grid_size=grid_size, base_activation=base_activation, grid_range=grid_range,
+                    dropout=conv_dropout, l1_decay=l1_decay, groups=groups, norm_layer=kan_norm_layer, affine=affine, degree=degree)
+        args.update({k: v for k, v in kwargs.items() if k in signature(make).parameters})
+        block = partial(make, **args)
+        self.arch = arch
+        first = dict(kernel_size=11, stride=4, padding=2) if arch == "default" else dict(kernel_size=5, stride=1, padding=2)
+        self.features = nn.Sequential(
+            block(input_channels, 64, groups=groups, **first), nn.MaxPool2d(kernel_size=3, stride=2),
+            block(64, 192, kernel_size=5, padding=2, groups=groups), nn.MaxPool2d(kernel_size=3, stride=2),
+            block(192, 384, kernel_size=3, padding=1, groups=groups),
+            block(384, 256, kernel_size=3, padding=1, groups=groups),
+            block(256, 256, kernel_size=3, padding=1, groups=groups), nn.MaxPool2d(kernel_size=3, stride=2))
+        self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
+        hid = 4096 if arch == "default" else 1024
+        p = dropout if classifier_dropout is None else classifier_dropout
+        self.classifier = nn.Sequential()
+        for name, mod in (("head_dropout1", nn.Dropout(p=p)), ("fc1", nn.Linear(256 * 6 * 6, hid)), ("relu1", nn.ReLU(True)),
+                          ("head_dropout2", nn.Dropout(p=p)), ("fc2", nn.Linear(hid, hid)), ("relu2", nn.ReLU(True)),
+                          ("fc3", nn.Linear(hid, num_classes))):
+            self.classifier.add_module(name, mod)
+        self._initialize_weights()
+        self.name = f"AlexNet_{classifier_type}_{kan_conv.upper()}"
+
+    def _initialize_weights(self) -> None:
+        # kan_alexnet.py:236-250: every nn.Conv2d (including the KAN layers' weight holders) is re-initialised
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.InstanceNorm2d, nn.GroupNorm)):
+                if m.weight is not None:
+                    nn.init.constant_(m.weight, 1)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.avgpool(self.features(x))
+        return self.classifier(torch.flatten(x, 1))
+
+
+def alexnet_kan(num_classes: int = 1000, input_channels: int = 3, dropout: float = 0.5, arch: str = "default",
+                conv_type: str = "kanconv", kan_conv: Optional[str] = "KAN", classifier_type: str = "Linear", **kwargs: Any) -> AlexNetKAN:
+    if conv_type != "kanconv":
+        raise NotImplementedError("only conv_type='kanconv' is on the accelerated path")
+    kwargs.pop("kan_classifier", None)
+    return AlexNetKAN(num_classes=num_classes, dropout=dropout, input_channels=input_channels, arch=arch,
+                      kan_conv=kan_conv or "KAN", classifier_type=classifier_type, **kwargs)

@@ -1,0 +1,334 @@
+"""Autograd operators over the libkanconv C ABI.
+
+Two differentiable entry points, both launching only hand-written HIP kernels:
+
+* ``kan_conv``           -- the fused "expand to basis planes + convolve" stage
+                            (reference: kan_layers.py:199-239, fast_kan_layers.py:103-109,
+                            cheby_kan_layers.py:93-97).
+* ``kan_conv_in_prelu``  -- the same followed by InstanceNorm2d [+ PReLU]
+                            (kan_layers.py:241-243, cheby_kan_layers.py:98).
+* ``instance_norm``      -- InstanceNorm2d alone (fast_kan_layers.py:106, norm on the input).
+
+All tensors are fp32, NCHW, on a ROCm device.  Groups (kan_layers.py:249-258) are handled
+as one launch per group on channel-offset pointers; nothing is copied or concatenated.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+@dataclass(frozen=True)
+class ConvSpec:
+    """Static description of one layer's conv stage (hashable: used as a plan-cache key)."""
+    kind: int
+    n_basis: int
+    order: int
+    act: int                      # L.ACT_NONE => no base branch
+    p0: float
+    p1: float
+    table: Tuple[float, ...]
+    kernel: Tuple[int, int]
+    stride: Tuple[int, int]
+    padding: Tuple[int, int]
+    dilation: Tuple[int, int]
+    groups: int = 1
+
+    @property
+    def has_base(self) -> bool:
+        return self.act != L.ACT_NONE
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        (kh, kw), (sh, sw), (ph, pw), (dh, dw) = self.kernel, self.stride, self.padding, self.dilation
+        return (H + 2 * ph - dh * (kh - 1) - 1) // sh + 1, (W + 2 * pw - dw * (kw - 1) - 1) // sw + 1
+
+
+def _basis_struct(spec: ConvSpec) -> L.KanBasis:
+    b = L.KanBasis()
+    b.kind, b.n_basis, b.order, b.act, b.p0, b.p1 = spec.kind, spec.n_basis, spec.order, spec.act, spec.p0, spec.p1
+    if len(spec.table) > L.KAN_MAX_TABLE:
+        raise L.KanConvError(f"basis table of {len(spec.table)} entries exceeds KAN_MAX_TABLE={L.KAN_MAX_TABLE}")
+    for i, v in enumerate(spec.table):
+        b.table[i] = v
+    return b
+
+
+@lru_cache(maxsize=512)
+def _plan_cached(spec: ConvSpec, B: int, Cg: int, H: int, W: int, Og: int, C_total: int, O_total: int):
+    Ho, Wo = spec.out_hw(H, W)
+    if Ho <= 0 or Wo <= 0:
+        raise L.KanConvError(f"empty output ({Ho}x{Wo}) for input {H}x{W}")
+    g = L.KanGeom()
+    g.B, g.C, g.H, g.W, g.O, g.Ho, g.Wo = B, Cg, H, W, Og, Ho, Wo
+    (g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw) = spec.kernel, spec.stride, spec.padding, spec.dilation
+    g.x_bstride, g.y_bstride = C_total * H * W, O_total * Ho * Wo
+    b = _basis_struct(spec)
+    p = L.KanPlan()
+    L.check(L.load().kan_plan(C.byref(g), C.byref(b), C.byref(p)), "kan_plan")
+    return g, b, p
+
+
+def _ptr(t: Optional[torch.Tensor], offset: int = 0) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr() + 4 * offset)
+
+
+def _stream(t: torch.Tensor) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _require(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise L.KanConvError(f"{name} is on {t.device}: this path runs only on a ROCm device (MI355X); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise L.KanConvError(f"{name} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def _split_weights(spec: ConvSpec, weights: Sequence[torch.Tensor]):
+    G = spec.groups
+    if spec.has_base:
+        return list(weights[:G]), list(weights[G:2 * G])
+    return [None] * G, list(weights[:G])
+
+
+# --------------------------------------------------------------------------------------- raw stages
+def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis):
+    """Returns (z_slabs [S,B,O,Ho,Wo], packed weights per group, geom, basis, plan)."""
+    lib = L.load()
+    B, Ct, H, W = x.shape
+    G = spec.groups
+    Cg, Og = Ct // G, w_basis[0].shape[0]
+    Ot = Og * G
+    geom, basis, plan = _plan_cached(spec, B, Cg, H, W, Og, Ct, Ot)
+    Ho, Wo = geom.Ho, geom.Wo
+    st = _stream(x)
+    z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
+    packed = []
+    for g in range(G):
+        wp = torch.empty(plan.Kpad * plan.Opad, device=x.device, dtype=torch.float32)
+        L.check(lib.kan_pack_weights(_ptr(w_base[g]), _ptr(w_basis[g]), _ptr(wp), C.byref(geom), C.byref(basis), st), "kan_pack_weights")
+        L.check(lib.kan_conv_fwd(_ptr(x, g * Cg * H * W), _ptr(xn if xn is not None else x, g * Cg * H * W), _ptr(wp),
+                                 _ptr(z, g * Og * Ho * Wo), C.byref(geom), C.byref(basis), st), "kan_conv_fwd")
+        packed.append(wp)
+    return z, packed, geom, basis, plan
+
+
+def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool):
+    """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list)."""
+    lib = L.load()
+    B, Ct, H, W = x.shape
+    G = spec.groups
+    Cg = Ct // G
+    Ot = dz.shape[1]
+    Og = Ot // G
+    geom, basis, plan = _plan_cached(spec, B, Cg, H, W, Og, Ct, Ot)
+    Ho, Wo = geom.Ho, geom.Wo
+    kh, kw = spec.kernel
+    st = _stream(x)
+    xs = xn if xn is not None else x
+    dw_base: List[Optional[torch.Tensor]] = [None] * G
+    dw_basis: List[Optional[torch.Tensor]] = [None] * G
+    if need_w:
+        dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
+        for g in range(G):
+            L.check(lib.kan_conv_bwd_weight(_ptr(dz, g * Og * Ho * Wo), _ptr(x, g * Cg * H * W), _ptr(xs, g * Cg * H * W), _ptr(dwp),
+                                            C.byref(geom), C.byref(basis), st), "kan_conv_bwd_weight")
+            if spec.has_base:
+                dw_base[g] = torch.empty((Og, Cg, kh, kw), device=x.device, dtype=torch.float32)
+            dw_basis[g] = torch.empty((Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
+            L.check(lib.kan_unpack_wgrad(_ptr(dwp), _ptr(dw_base[g]), _ptr(dw_basis[g]), C.byref(geom), C.byref(basis), st), "kan_unpack_wgrad")
+    dx = dxn = None
+    if need_x or need_xn:
+        S = plan.bwd_data_splits
+        separate = xn is not None
+        dxs = torch.empty((S, B, Ct, H, W), device=x.device, dtype=torch.float32)
+        dxns = torch.empty_like(dxs) if separate else None
+        for g in range(G):
+            off = g * Cg * H * W
+            L.check(lib.kan_conv_bwd_data(_ptr(dz, g * Og * Ho * Wo), _ptr(x, off), _ptr(xs, off), _ptr(packed[g]),
+                                          _ptr(dxs, off), _ptr(dxns, off) if separate else C.c_void_p(0),
+                                          C.byref(geom), C.byref(basis), st), "kan_conv_bwd_data")
+        dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
+    return dx, dxn, dw_base, dw_basis
+
+
+def _sum_slabs(slabs: torch.Tensor, B: int, Cn: int, HW: int) -> torch.Tensor:
+    """[S,B,Cn,...] partial slabs -> their sum (kan_slab_reduce); S == 1 is a view."""
+    if slabs.shape[0] == 1:
+        return slabs[0]
+    out = torch.empty_like(slabs[0])
+    L.check(L.load().kan_slab_reduce(_ptr(slabs), slabs.shape[0], slabs[0].numel(), _ptr(out), B, Cn, HW, Cn * HW, _stream(slabs)),
+            "kan_slab_reduce")
+    return out
+
+
+def _flat_grads(spec: ConvSpec, dw_base, dw_basis):
+    return tuple(dw_base) + tuple(dw_basis) if spec.has_base else tuple(dw_basis)
+
+
+# --------------------------------------------------------------------------------------- autograd
+class _KanConv(torch.autograd.Function):
+    """z = conv stage.  args: spec, x, xn (or None), *[w_base_g...], *[w_basis_g...]"""
+
+    @staticmethod
+    def forward(ctx, spec: ConvSpec, x, xn, *weights):
+        x = _require(x, "x")
+        xn = _require(xn, "xn") if xn is not None else None
+        weights = [_require(w, "weight") for w in weights]
+        w_base, w_basis = _split_weights(spec, weights)
+        with torch.cuda.device(x.device):
+            z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis)
+            z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
+        ctx.spec, ctx.has_xn, ctx.n_w = spec, xn is not None, len(weights)
+        ctx.save_for_backward(x, *( [xn] if xn is not None else [] ), *packed)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        saved = ctx.saved_tensors
+        x = saved[0]
+        xn = saved[1] if ctx.has_xn else None
+        packed = saved[1 + int(ctx.has_xn):]
+        need_x, need_xn = ctx.needs_input_grad[1], ctx.has_xn and ctx.needs_input_grad[2]
+        need_w = any(ctx.needs_input_grad[3:])
+        with torch.cuda.device(x.device):
+            dx, dxn, dwb, dws = _conv_backward(ctx.spec, x, xn, packed, dz.contiguous(), need_x, need_xn, need_w)
+        return (None, dx if need_x else None, dxn if need_xn else None) + _flat_grads(ctx.spec, dwb, dws)
+
+
+class _KanConvInPrelu(torch.autograd.Function):
+    """y = [PReLU](InstanceNorm(conv stage)).
+    args: spec, eps, use_affine, use_prelu, x, *[w_base_g], *[w_basis_g], *[gamma_g], *[beta_g], *[prelu_g]"""
+
+    @staticmethod
+    def forward(ctx, spec: ConvSpec, eps: float, use_affine: bool, use_prelu: bool, x, *params):
+        lib = L.load()
+        x = _require(x, "x")
+        params = [_require(p, "parameter") for p in params]
+        G = spec.groups
+        nw = G * (2 if spec.has_base else 1)
+        w_base, w_basis = _split_weights(spec, params[:nw])
+        rest = params[nw:]
+        gammas = rest[:G] if use_affine else [None] * G
+        betas = rest[G:2 * G] if use_affine else [None] * G
+        prelus = rest[2 * G * int(use_affine):] if use_prelu else [None] * G
+        if use_prelu and any(p.numel() != 1 for p in prelus):
+            raise L.KanConvError("only scalar-slope PReLU (nn.PReLU()) is supported, as in kan_layers.py:182")
+        with torch.cuda.device(x.device):
+            zs, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis)
+            S, B, Ot, Ho, Wo = zs.shape
+            Og, HW = Ot // G, Ho * Wo
+            y = torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
+            mean = torch.empty((G, B * Og), device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            st = _stream(x)
+            for g in range(G):
+                off = g * Og * HW
+                L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs, off), S, plan.fwd_slab_elems, _ptr(zs, off), _ptr(gammas[g]), _ptr(betas[g]),
+                                                   _ptr(prelus[g]), _ptr(y, off), _ptr(mean, g * B * Og), _ptr(rstd, g * B * Og),
+                                                   B, Og, HW, Ot * HW, eps, st), "kan_instnorm_prelu_fwd")
+        z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
+        ctx.spec, ctx.flags, ctx.n_params = spec, (use_affine, use_prelu), len(params)
+        ctx.save_for_backward(x, z, mean, rstd, *packed, *[t for t in list(gammas) + list(betas) + list(prelus) if t is not None])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        spec = ctx.spec
+        use_affine, use_prelu = ctx.flags
+        G = spec.groups
+        saved = ctx.saved_tensors
+        x, z, mean, rstd = saved[:4]
+        packed = saved[4:4 + G]
+        rest = list(saved[4 + G:])
+        gammas = rest[:G] if use_affine else [None] * G
+        betas = rest[G:2 * G] if use_affine else [None] * G
+        prelus = rest[2 * G * int(use_affine):] if use_prelu else [None] * G
+        dy = dy.contiguous()
+        B, Ot, Ho, Wo = dy.shape
+        Og, HW = Ot // G, Ho * Wo
+        with torch.cuda.device(x.device):
+            st = _stream(x)
+            dz = torch.empty_like(dy)
+            dgam = [torch.zeros_like(t) for t in gammas] if use_affine else [None] * G
+            dbet = [torch.zeros_like(t) for t in betas] if use_affine else [None] * G
+            dpre = [torch.zeros_like(t) for t in prelus] if use_prelu else [None] * G
+            for g in range(G):
+                off = g * Og * HW
+                L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy, off), _ptr(z, off), _ptr(mean, g * B * Og), _ptr(rstd, g * B * Og),
+                                                   _ptr(gammas[g]), _ptr(betas[g]), _ptr(prelus[g]), _ptr(dz, off),
+                                                   _ptr(dgam[g]), _ptr(dbet[g]), _ptr(dpre[g]), B, Og, HW, Ot * HW, st), "kan_instnorm_prelu_bwd")
+            nw = G * (2 if spec.has_base else 1)
+            need_x = ctx.needs_input_grad[4]
+            need_w = any(ctx.needs_input_grad[5:5 + nw])
+            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w)
+        grads = _flat_grads(spec, dwb, dws)
+        if use_affine:
+            grads += tuple(dgam) + tuple(dbet)
+        if use_prelu:
+            grads += tuple(dpre)
+        return (None, None, None, None, dx if need_x else None) + grads
+
+
+class _InstanceNorm(torch.autograd.Function):
+    """InstanceNorm2d over NCHW (args: x, gamma|None, beta|None, eps)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps: float):
+        lib = L.load()
+        x = _require(x, "x")
+        B, Cn, H, W = x.shape
+        with torch.cuda.device(x.device):
+            y = torch.empty_like(x)
+            mean = torch.empty(B * Cn, device=x.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            L.check(lib.kan_instnorm_prelu_fwd(_ptr(x), 1, 0, _ptr(x), _ptr(gamma), _ptr(beta), C.c_void_p(0), _ptr(y), _ptr(mean), _ptr(rstd),
+                                               B, Cn, H * W, Cn * H * W, eps, _stream(x)), "kan_instnorm_prelu_fwd")
+        ctx.affine = gamma is not None
+        ctx.save_for_backward(x, mean, rstd, *([gamma, beta] if gamma is not None else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        saved = ctx.saved_tensors
+        x, mean, rstd = saved[:3]
+        gamma, beta = (saved[3], saved[4]) if ctx.affine else (None, None)
+        dy = dy.contiguous()
+        B, Cn, H, W = x.shape
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x)
+            dg = torch.zeros_like(gamma) if ctx.affine else None
+            db = torch.zeros_like(beta) if ctx.affine else None
+            L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), C.c_void_p(0), _ptr(dx),
+                                               _ptr(dg), _ptr(db), C.c_void_p(0), B, Cn, H * W, Cn * H * W, _stream(x)), "kan_instnorm_prelu_bwd")
+        return dx, dg, db, None
+
+
+# --------------------------------------------------------------------------------------- public API
+def kan_conv(spec: ConvSpec, x: torch.Tensor, xn: Optional[torch.Tensor], w_base: Sequence[torch.Tensor],
+             w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
+    ws = (list(w_base) if spec.has_base else []) + list(w_basis)
+    return _KanConv.apply(spec, x, xn, *ws)
+
+
+def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Tensor], w_basis: Sequence[torch.Tensor],
+                      gammas: Optional[Sequence[torch.Tensor]], betas: Optional[Sequence[torch.Tensor]],
+                      prelus: Optional[Sequence[torch.Tensor]], eps: float = 1e-5) -> torch.Tensor:
+    ws = (list(w_base) if spec.has_base else []) + list(w_basis)
+    aff = gammas is not None
+    extra = (list(gammas) + list(betas) if aff else []) + (list(prelus) if prelus is not None else [])
+    return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, x, *ws, *extra)
+
+
+def instance_norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    return _InstanceNorm.apply(x, gamma, beta, float(eps))

@@ -1,0 +1,150 @@
+/*
+ * kanconv.h -- C ABI of libkanconv.so: MI355X (gfx950) kernels for the conv-KAN hot path.
+ *
+ * The reference (GadGadGad/Convolutional-KAN-for-Image-Classification) has NO native
+ * interface for this path: it is ~60 eager ATen ops per layer call.  The entry points
+ * below are what a ctypes/cffi binding placed inside the reference's layer classes would
+ * call instead of those op sequences.  Each declaration cites the
+ * reference lines it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to contiguous fp32 unless stated otherwise;
+ *   - the caller owns every buffer, including workspaces; the library never allocates,
+ *     frees or synchronises the device; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*);
+ *   - return value: 0 on success, <0 on error; message via kan_last_error() (thread-local);
+ *   - no C++ exception crosses the boundary; no mutable global state.
+ *
+ * Tensor layouts: activations NCHW; one "group" of the reference layer per call, so a
+ * grouped layer is G calls whose x / y pointers are offset by the group's first channel
+ * and whose batch strides (`x_bstride`, `y_bstride`) are those of the FULL tensors.
+ */
+#ifndef KANCONV_H
+#define KANCONV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAN_MAX_PLANES 16   /* basis planes per input channel incl. the base-activation plane */
+#define KAN_MAX_TABLE  32   /* knots (B-spline) or centres (RBF) */
+
+/* basis families */
+enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2 };
+/* base-branch activations; KAN_ACT_NONE = layer has no base branch (ChebyKAN) */
+enum { KAN_ACT_NONE = -1, KAN_ACT_IDENTITY = 0, KAN_ACT_GELU = 1, KAN_ACT_SILU = 2, KAN_ACT_RELU = 3,
+       KAN_ACT_TANH = 4, KAN_ACT_SIGMOID = 5, KAN_ACT_GELU_TANH = 6 };
+
+/* Geometry of ONE group's convolution (all fields in elements, not bytes). */
+typedef struct KanGeom {
+    int B, C, H, W;              /* input block: batch, channels of this group, height, width */
+    int O, Ho, Wo;               /* output block of this group */
+    int kh, kw, sh, sw, ph, pw, dh, dw;
+    long long x_bstride;         /* distance between images in x / dx  (C_total*H*W)   */
+    long long y_bstride;         /* distance between images in z / dz  (O_total*Ho*Wo) */
+} KanGeom;
+
+/* Basis description.
+ *   B-spline : n_basis = grid_size + spline_order, order = spline_order,
+ *              table[0 .. n_basis+order] = the fp32 knots of torch.linspace
+ *              (layers/kan_layers.py:184-190)
+ *   RBF      : n_basis = grid_size, table[0..n_basis-1] = centres, p0 = denominator
+ *              (utils/utils.py:28-30)
+ *   Chebyshev: n_basis = degree + 1, p0 / p1 = clamp bounds (-1+1e-7, 1-1e-7 as fp32)
+ *              (layers/cheby_kan_layers.py:93-96)
+ * `act` is the base-branch activation (KAN_ACT_NONE: no base branch, no base weight).
+ * Planes per channel P = n_basis + (act != KAN_ACT_NONE); P <= KAN_MAX_PLANES. */
+typedef struct KanBasis {
+    int kind, n_basis, order, act;
+    float p0, p1;
+    float table[KAN_MAX_TABLE];
+} KanBasis;
+
+/* Launch plan for one geometry: split counts and workspace sizes (bytes). */
+typedef struct KanPlan {
+    int P;                        /* planes per channel */
+    int K;                        /* GEMM depth of the forward conv: C*kh*kw*P */
+    int Kpad, Opad;               /* padded dims of the packed weight matrix [Kpad][Opad] */
+    int fwd_splits;               /* z is written as fwd_splits partial slabs */
+    int bwd_data_splits;          /* dx is written as bwd_data_splits partial slabs */
+    int bwd_weight_splits;        /* packed dW is written as bwd_weight_splits partial slabs */
+    long long packed_weight_bytes;    /* Kpad*Opad*4 */
+    long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */
+    long long bwd_data_slab_elems;    /* B*x_bstride      : stride between dx slabs */
+    long long bwd_weight_slab_elems;  /* Kpad*Opad        : stride between dW slabs */
+} KanPlan;
+
+const char* kan_version(void);
+const char* kan_last_error(void);
+
+/* Fill `plan` for (geom, basis).  Pure host arithmetic, no device work. */
+int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
+
+/* Pack the reference-layout weights of one group into the GEMM layout used by all three
+ * conv kernels:  wp[((c*T + tap)*P + p)][o],  T = kh*kw,  plane p = 0 is the base branch
+ * (if any), planes hb.. are basis k = p - hb.  Replaces nothing in the reference (layout
+ * only); sources are  base_conv[g].weight [O,C,kh,kw]  (kan_layers.py:159-166) and
+ * spline_conv[g].weight / poly_conv[g].weight [O,C*n_basis,kh,kw], channel c*n_basis+k
+ * (kan_layers.py:170-177,237; fast_kan_layers.py:68-75,107; cheby_kan_layers.py:77-84,95).
+ * `w_base` may be NULL iff basis->act == KAN_ACT_NONE. */
+int kan_pack_weights(const float* w_base, const float* w_basis, float* wp,
+                     const KanGeom* geom, const KanBasis* basis, void* stream);
+
+/* Fused forward:  z = act(x) (*) W_base + sum_k basis_k(xn) (*) W_basis[:, c*n+k]
+ * with zero padding applied to the EXPANDED operand.  Replaces
+ *   kan_layers.py:199-200, 203-239   (B-spline: activation, knot broadcast, indicator,
+ *                                     Cox-de Boor, moveaxis/flatten, two convs, add)
+ *   fast_kan_layers.py:103, 106-109  (RBF; xn = normalised input, x = raw input)
+ *   cheby_kan_layers.py:93-97        (Chebyshev; no base branch)
+ * `xn` is the tensor the basis is evaluated on (== x except for FastKAN).
+ * z holds plan.fwd_splits slabs of plan.fwd_slab_elems elements; their sum is the result
+ * (kan_instnorm_prelu_fwd / kan_slab_reduce consume slabs directly). */
+int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z,
+                 const KanGeom* geom, const KanBasis* basis, void* stream);
+
+/* Gradient w.r.t. the input (autograd of the sites listed at kan_conv_fwd):
+ *   dx  = act'(x) * dgrad(dz, W_base)              (base branch)
+ *   dxn = sum_k basis_k'(xn) * dgrad(dz, W_basis)_k
+ * If dxn == NULL the two are summed into dx (valid when xn == x).  Both are written as
+ * plan.bwd_data_splits slabs of plan.bwd_data_slab_elems elements. */
+int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wp,
+                      float* dx, float* dxn,
+                      const KanGeom* geom, const KanBasis* basis, void* stream);
+
+/* Gradient w.r.t. the packed weights: dwp[k][o] = sum_pixels expanded[k][pixel] * dz[o][pixel],
+ * written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
+int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,
+                        const KanGeom* geom, const KanBasis* basis, void* stream);
+
+/* Sum the dwp slabs and scatter back to the reference layouts (inverse of kan_pack_weights).
+ * dw_base may be NULL iff there is no base branch. */
+int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis,
+                     const KanGeom* geom, const KanBasis* basis, void* stream);
+
+/* out = sum_s slabs[s]  over an NCHW block (B, Cn channels, HW pixels, batch stride bstride). */
+int kan_slab_reduce(const float* slabs, int n_slabs, long long slab_elems, float* out,
+                    int B, int Cn, int HW, long long bstride, void* stream);
+
+/* InstanceNorm2d (eps, biased variance, per (b,channel) plane, optional affine gamma/beta)
+ * followed by an optional scalar-slope PReLU; replaces kan_layers.py:241-243
+ * (layer_norm -> prelus), cheby_kan_layers.py:98 and fast_kan_layers.py:106 (norm only:
+ * pass prelu_a = NULL).  `z` holds n_slabs partial slabs (their sum is normalised); the
+ * summed pre-norm value is written to z_out (may alias slab 0), which the backward needs.
+ * mean / rstd: [B*Cn] outputs saved for the backward. */
+int kan_instnorm_prelu_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out,
+                           const float* gamma, const float* beta, const float* prelu_a,
+                           float* y, float* mean, float* rstd,
+                           int B, int Cn, int HW, long long bstride, float eps, void* stream);
+
+/* Backward of the above.  dz <- gradient w.r.t. the summed pre-norm value.
+ * dgamma/dbeta ([Cn]) and dprelu ([1]) are ACCUMULATED with atomics: zero them first.
+ * Any of gamma/prelu_a/dgamma/dbeta/dprelu may be NULL when that feature is off. */
+int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
+                           const float* gamma, const float* beta, const float* prelu_a,
+                           float* dz, float* dgamma, float* dbeta, float* dprelu,
+                           int B, int Cn, int HW, long long bstride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KANCONV_H */

@@ -1,0 +1,206 @@
+"""CPU oracle for the KAN-conv hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module.  The product path (``convkan_amd``) never calls into it and has no
+CPU fallback.
+
+What it is: a plain PyTorch-CPU restatement, in this repo's own words, of the op sequence
+the reference executes for its three conv-KAN layers.  The convolutions, InstanceNorm and
+PReLU themselves live in PyTorch/ATen (an un-vendored dependency of the reference; this
+image ships torch 2.10.0), exactly as they do for the reference, so the oracle calls the
+same ATen CPU operators.
+
+Parity pin: every function below is checked against the *imported reference itself*
+(``/root/reference``, importable in the build container) by
+``tests/golden/make_golden.py`` -- which also freezes the reference's outputs as
+``tests/golden/*.npz`` -- and against those frozen vectors by ``tests/test_oracle.py``.
+
+Reference sites restated (all paths relative to /root/reference):
+  * layers/kan_layers.py:184-190   knot vector               -> bspline_knots
+  * layers/kan_layers.py:203-236   order-0 indicator + Cox-de Boor -> bspline_basis
+  * layers/kan_layers.py:197-247   forward_kan               -> kan_conv2d
+  * layers/kan_layers.py:249-258   group split / concat      -> _per_group
+  * utils/utils.py:19-33           RadialBasisFunction       -> rbf_grid / rbf_basis
+  * layers/fast_kan_layers.py:100-120 forward_fast_kan       -> fastkan_conv2d
+  * layers/cheby_kan_layers.py:91-111 forward_ChebyKAN       -> chebykan_conv2d
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------- bases
+def bspline_knots(grid_size: int, spline_order: int, grid_range: Sequence[float]) -> Tensor:
+    """Uniform extended knot vector (kan_layers.py:184-190): G + 2S + 1 fp32 knots."""
+    lo, hi = float(grid_range[0]), float(grid_range[1])
+    step = (hi - lo) / grid_size
+    return torch.linspace(lo - step * spline_order, hi + step * spline_order,
+                          grid_size + 2 * spline_order + 1, dtype=torch.float32)
+
+
+def bspline_basis(x: Tensor, knots: Tensor, spline_order: int) -> Tensor:
+    """B-spline bases of ``x`` appended as a last axis of length G+S (kan_layers.py:203-236).
+
+    Level 0 is the half-open interval indicator; level k blends neighbours with the
+    Cox-de Boor weights.  Zero-width knot spans get denominator 1 as in the reference.
+    """
+    g = knots.to(device=x.device, dtype=x.dtype)
+    xe = x.unsqueeze(-1)
+    basis = torch.logical_and(xe >= g[:-1], xe < g[1:]).to(x.dtype)
+    one = torch.ones((), dtype=x.dtype, device=x.device)
+    for k in range(1, spline_order + 1):
+        left, right = g[:-(k + 1)], g[k + 1:]
+        span_l = g[k:-1] - left
+        span_r = right - g[1:-k]
+        span_l = torch.where(span_l == 0, one, span_l)
+        span_r = torch.where(span_r == 0, one, span_r)
+        basis = (xe - left) / span_l * basis[..., :-1] + (right - xe) / span_r * basis[..., 1:]
+    return basis
+
+
+def rbf_grid(grid_size: int, grid_range: Sequence[float]):
+    """Centres and width of the FastKAN RBFs (utils/utils.py:28-30)."""
+    lo, hi = float(grid_range[0]), float(grid_range[1])
+    centres = torch.linspace(lo, hi, grid_size)
+    denom = (hi - lo) / (grid_size - 1)
+    return centres, denom
+
+
+def rbf_basis(x: Tensor, centres: Tensor, denom: float) -> Tensor:
+    """exp(-((x - c_g)/d)^2) on a new last axis (utils/utils.py:32-33)."""
+    return torch.exp(-(((x.unsqueeze(-1) - centres.to(x)) / denom) ** 2))
+
+
+def cheby_basis(x: Tensor, degree: int, eps: float = 1e-7) -> Tensor:
+    """T_k(tanh x) = cos(k acos(clamp(tanh x))) on a new axis 2 (cheby_kan_layers.py:93-96)."""
+    theta = torch.acos(torch.clamp(torch.tanh(x).unsqueeze(2), -1 + eps, 1 - eps))
+    k = torch.arange(0, degree + 1, device=x.device).view(1, 1, -1, *([1] * (x.dim() - 2)))
+    return torch.cos(theta * k)
+
+
+def _planes_to_channels(b: Tensor) -> Tensor:
+    """[B,C,H,W,K] -> [B,C*K,H,W] with channel index c*K+k (kan_layers.py:237)."""
+    return b.movedim(-1, 2).flatten(1, 2)
+
+
+# --------------------------------------------------------------------------- layers
+def _per_group(x: Tensor, groups: int, fn: Callable[[Tensor, int], Tensor]) -> Tensor:
+    parts = torch.chunk(x, groups, dim=1) if groups > 1 else (x,)
+    return torch.cat([fn(p, g) for g, p in enumerate(parts)], dim=1)
+
+
+def _conv(x, w, stride, padding, dilation):
+    return F.conv2d(x, w, None, stride, padding, dilation, 1)
+
+
+def kan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_spline: Sequence[Tensor], prelu_a: Sequence[Tensor],
+               *, knots: Tensor, spline_order: int, act: Optional[Callable[[Tensor], Tensor]],
+               stride=1, padding=0, dilation=1, groups: int = 1,
+               norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None,
+               pre_norm_out: Optional[list] = None) -> Tensor:
+    """B-spline KAN conv layer (kan_layers.py:197-258).
+
+    ``norm[g]`` is the output normalisation of group g; ``None`` means InstanceNorm2d with
+    eps 1e-5, no affine (the reference's constructor default).  ``pre_norm_out`` (a list)
+    receives the pre-normalisation sums, for tests of the conv stage alone.
+    """
+    def one(xg, g):
+        a = xg if act is None else act(xg)
+        z = _conv(a, w_base[g], stride, padding, dilation)
+        planes = _planes_to_channels(bspline_basis(xg, knots, spline_order).contiguous())
+        z = z + _conv(planes, w_spline[g], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        return F.prelu(n, prelu_a[g])
+    return _per_group(x, groups, one)
+
+
+def fastkan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_spline: Sequence[Tensor],
+                   *, centres: Tensor, denom: float, act: Optional[Callable[[Tensor], Tensor]],
+                   stride=1, padding=0, dilation=1, groups: int = 1,
+                   norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None) -> Tensor:
+    """FastKAN conv layer (fast_kan_layers.py:100-120): norm acts on the *input* of the RBFs."""
+    def one(xg, g):
+        a = xg if act is None else act(xg)
+        z = _conv(a, w_base[g], stride, padding, dilation)
+        xn = F.instance_norm(xg, eps=1e-5) if norm is None else norm[g](xg)
+        planes = _planes_to_channels(rbf_basis(xn, centres, denom))
+        return z + _conv(planes, w_spline[g], stride, padding, dilation)
+    return _per_group(x, groups, one)
+
+
+def chebykan_conv2d(x: Tensor, w_poly: Sequence[Tensor], *, degree: int,
+                    stride=1, padding=0, dilation=1, groups: int = 1,
+                    norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None,
+                    pre_norm_out: Optional[list] = None) -> Tensor:
+    """ChebyKAN conv layer (cheby_kan_layers.py:91-111): no base branch, no activation."""
+    def one(xg, g):
+        planes = cheby_basis(xg, degree).flatten(1, 2)
+        z = _conv(planes, w_poly[g], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        return F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+    return _per_group(x, groups, one)
+
+
+# --------------------------------------------------------------------------- whole-model oracle
+VGG11_CFG = [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512]
+
+
+class OracleKANConv2d(torch.nn.Module):
+    """Parameter holder + ``kan_conv2d`` call; used by the CPU baseline model only."""
+
+    def __init__(self, cin, cout, kernel_size=3, padding=1, grid_size=5, spline_order=3,
+                 grid_range=(-1.0, 1.0), act=F.silu):
+        super().__init__()
+        nb = grid_size + spline_order
+        self.w_base = torch.nn.Parameter(torch.empty(cout, cin, kernel_size, kernel_size))
+        self.w_spline = torch.nn.Parameter(torch.empty(cout, cin * nb, kernel_size, kernel_size))
+        self.prelu = torch.nn.Parameter(torch.full((1,), 0.25))
+        torch.nn.init.kaiming_uniform_(self.w_base, nonlinearity="linear")
+        torch.nn.init.kaiming_uniform_(self.w_spline, nonlinearity="linear")
+        self.knots = bspline_knots(grid_size, spline_order, grid_range)
+        self.spline_order, self.padding, self.act = spline_order, padding, act
+
+    def forward(self, x):
+        return kan_conv2d(x, [self.w_base], [self.w_spline], [self.prelu], knots=self.knots,
+                          spline_order=self.spline_order, act=self.act, padding=self.padding)
+
+
+class OracleKANVGG(torch.nn.Module):
+    """KAN-VGG (models/kan_vgg.py:73-188 composition): KAN convs + MaxPool(2,2), then
+    AdaptiveAvgPool(1,1) -> flatten -> Dropout(0.5) -> Linear."""
+
+    def __init__(self, cfg=VGG11_CFG, in_ch=3, num_classes=10, width_scale=1):
+        super().__init__()
+        feats, c = [], in_ch
+        for v in cfg:
+            if v == "M":
+                feats.append(torch.nn.MaxPool2d(2, 2))
+            else:
+                feats.append(OracleKANConv2d(c, v * width_scale))
+                c = v * width_scale
+        self.features = torch.nn.ModuleList(feats)
+        self.classifier = torch.nn.Sequential(torch.nn.Dropout(0.5), torch.nn.Linear(c, num_classes))
+
+    def forward(self, x):
+        for f in self.features:
+            x = f(x)
+        x = F.adaptive_avg_pool2d(x, (1, 1)).flatten(1)
+        return self.classifier(x)
+
+
+def flops_kan_conv(B, C, O, Ho, Wo, kh, kw, n_planes):
+    """Dense algorithmic FLOPs of one conv stage, forward only."""
+    return 2.0 * B * O * Ho * Wo * C * n_planes * kh * kw
+
+
+__all__ = [n for n in dir() if not n.startswith("_")]
+_ = math

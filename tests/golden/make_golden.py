@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  For every case it
+  1. builds the reference layer (imported unmodified from /root/reference/layers),
+  2. runs forward + backward on explicit, saved inputs,
+  3. checks this repo's CPU oracle (oracle/kan_oracle.py) against the reference result
+     (this is the oracle's pin; the script aborts on any mismatch), and
+  4. freezes inputs, every state_dict tensor, outputs and all gradients into an .npz.
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import importlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+sys.dont_write_bytecode = True
+
+from layers import KANConv2DLayer, FastKANConv2DLayer, ChebyKANConv2DLayer  # noqa: E402  (reference)
+from oracle import kan_oracle as O  # noqa: E402
+
+ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+NORMS = {"in": nn.InstanceNorm2d, "bn": nn.BatchNorm2d}
+ACT_FN = {"gelu": F.gelu, "silu": F.silu, "none": None, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+
+
+def det_fill(t: torch.Tensor, salt: int, scale: float):
+    """Machine-independent pseudo-random fill (no RNG): scale * sin(phi*i + salt)."""
+    i = torch.arange(t.numel(), dtype=torch.float64)
+    t.copy_((scale * torch.sin(i * 0.6180339887498949 * 7.0 + salt * 1.2345 + 0.1)).to(torch.float32).view_as(t))
+
+
+def mk_input(shape, salt, scale):
+    g = torch.Generator().manual_seed(1000 + salt)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ---------------------------------------------------------------------------------- cases
+def C(kind, name, B, Cin, Cout, H, W, k=3, s=1, p=1, d=1, groups=1, xs=1.0, **kw):
+    c = dict(kind=kind, name=name, B=B, C=Cin, O=Cout, H=H, W=W, k=k, s=s, p=p, d=d, groups=groups, xscale=xs)
+    c.update(kw)
+    return c
+
+
+CASES = [
+    # ---- B-spline (kan_layers.py)
+    C("bspline", "tiny", 2, 3, 4, 8, 8),
+    C("bspline", "odd", 2, 3, 5, 7, 5),
+    C("bspline", "stride2", 2, 4, 6, 9, 9, s=2),
+    C("bspline", "pad0", 2, 3, 4, 8, 8, p=0),
+    C("bspline", "pad2", 2, 3, 4, 6, 6, p=2),
+    C("bspline", "dil2", 2, 3, 4, 9, 9, d=2, p=2),
+    C("bspline", "k1", 2, 5, 7, 6, 6, k=1, p=0),
+    C("bspline", "k5", 2, 3, 4, 9, 9, k=5, p=2),
+    C("bspline", "k11s4", 1, 3, 8, 35, 35, k=11, s=4, p=2),
+    C("bspline", "groups2", 2, 4, 6, 8, 8, groups=2),
+    C("bspline", "depthwise", 2, 4, 8, 8, 8, groups=4),
+    C("bspline", "grid3", 2, 3, 4, 8, 8, grid_size=3),
+    C("bspline", "grid8", 2, 3, 4, 8, 8, grid_size=8),
+    C("bspline", "order1", 2, 3, 4, 8, 8, spline_order=1),
+    C("bspline", "order2", 2, 3, 4, 8, 8, spline_order=2),
+    C("bspline", "silu", 2, 3, 4, 8, 8, act="silu"),
+    C("bspline", "noact", 2, 3, 4, 8, 8, act="none"),
+    C("bspline", "relu", 2, 3, 4, 8, 8, act="relu"),
+    C("bspline", "affine", 2, 3, 4, 8, 8, norm_kwargs={"affine": True}),
+    C("bspline", "batchnorm", 3, 3, 4, 8, 8, norm="bn"),
+    C("bspline", "x3", 2, 3, 4, 8, 8, xs=3.0),
+    C("bspline", "range2", 2, 3, 4, 8, 8, grid_range=[-2.0, 2.0], xs=2.0),
+    C("bspline", "wide", 3, 20, 40, 6, 6, act="silu"),
+    C("bspline", "vgg_l6", 8, 24, 40, 2, 2, act="silu"),
+    C("bspline", "config1", 16, 3, 16, 32, 32, save_z=False),                     # README.md:88-93, BASELINE.json configs[0]
+    # ---- FastKAN / RBF (fast_kan_layers.py)
+    C("rbf", "tiny", 2, 3, 4, 8, 8),
+    C("rbf", "pad0", 2, 3, 4, 8, 8, p=0),
+    C("rbf", "groups2", 2, 4, 6, 8, 8, groups=2),
+    C("rbf", "grid5", 2, 3, 4, 8, 8, grid_size=5),
+    C("rbf", "gelu", 2, 3, 4, 8, 8, act="gelu"),
+    C("rbf", "x3", 2, 3, 4, 8, 8, xs=3.0),
+    C("rbf", "stride2", 2, 4, 6, 9, 9, s=2),
+    C("rbf", "affine", 2, 3, 4, 8, 8, norm_kwargs={"affine": True}),
+    C("rbf", "config2_p0", 2, 3, 64, 32, 32, p=0),                  # BASELINE.json configs[1] (ctor default padding)
+    C("rbf", "config2_p1", 1, 3, 64, 32, 32, p=1),                  # same through the factory ("same" padding)
+    # ---- ChebyKAN (cheby_kan_layers.py)
+    C("cheby", "tiny", 2, 3, 4, 8, 8),
+    C("cheby", "deg4", 2, 3, 4, 8, 8, degree=4),
+    C("cheby", "deg1", 2, 3, 4, 8, 8, degree=1),
+    C("cheby", "k11s4", 1, 3, 16, 64, 64, k=11, s=4, p=2, degree=4, norm_kwargs={"affine": True}),
+    C("cheby", "k5", 2, 6, 8, 9, 9, k=5, p=2, degree=4, norm_kwargs={"affine": True}),
+    C("cheby", "groups2", 2, 4, 6, 8, 8, groups=2),
+    C("cheby", "x3", 2, 3, 4, 8, 8, xs=3.0),
+    C("cheby", "x12", 2, 3, 4, 8, 8, xs=12.0),                      # tanh saturation / clamp-active region
+    C("cheby", "alex_l3", 1, 20, 32, 13, 13, degree=4, norm_kwargs={"affine": True}),
+]
+
+
+def build_ref(c):
+    kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
+    kw.update(c.get("norm_kwargs", {}))
+    if "norm" in c:
+        kw["norm_layer"] = NORMS[c["norm"]]
+    if c["kind"] == "bspline":
+        for key in ("grid_size", "spline_order", "grid_range"):
+            if key in c:
+                kw[key] = c[key]
+        if "act" in c:
+            kw["base_activation"] = ACTS[c["act"]]
+        return KANConv2DLayer(c["C"], c["O"], **kw)
+    if c["kind"] == "rbf":
+        for key in ("grid_size", "grid_range"):
+            if key in c:
+                kw[key] = c[key]
+        if "act" in c:
+            kw["base_activation"] = ACTS[c["act"]]
+        return FastKANConv2DLayer(c["C"], c["O"], **kw)
+    if "degree" in c:
+        kw["degree"] = c["degree"]
+    return ChebyKANConv2DLayer(c["C"], c["O"], **kw)
+
+
+def oracle_forward(c, layer, x, pre):
+    """Run the oracle with the reference layer's parameters."""
+    sd = dict(layer.named_parameters())
+    G = c["groups"]
+    norms = [layer.layer_norm[g] for g in range(G)]
+    geo = dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=G)
+    if c["kind"] == "bspline":
+        act = ACT_FN[c.get("act", "gelu")]
+        knots = O.bspline_knots(layer.grid_size, layer.spline_order, layer.grid_range)
+        assert torch.equal(knots, layer.grid)
+        return O.kan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)],
+                            [sd[f"spline_conv.{g}.weight"] for g in range(G)],
+                            [sd[f"prelus.{g}.weight"] for g in range(G)],
+                            knots=knots, spline_order=layer.spline_order, act=act, norm=norms,
+                            pre_norm_out=pre, **geo)
+    if c["kind"] == "rbf":
+        act = ACT_FN[c.get("act", "silu")]
+        centres, denom = O.rbf_grid(layer.grid_size, layer.grid_range)
+        assert torch.equal(centres, layer.rbf.grid.data) and denom == layer.rbf.denominator
+        return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)],
+                                [sd[f"spline_conv.{g}.weight"] for g in range(G)],
+                                centres=centres, denom=denom, act=act, norm=norms, **geo)
+    return O.chebykan_conv2d(x, [sd[f"poly_conv.{g}.weight"] for g in range(G)], degree=layer.degree,
+                             norm=norms, pre_norm_out=pre, **geo)
+
+
+def run_case(idx, c):
+    torch.manual_seed(idx)
+    layer = build_ref(c).train()
+    # machine-independent parameters (keeps fixtures reproducible without relying on RNG streams)
+    with torch.no_grad():
+        for j, (n, p) in enumerate(layer.named_parameters()):
+            if "prelus" in n:
+                p.fill_(0.25 if j % 2 else 0.1)
+            elif "layer_norm" in n and n.endswith("weight"):
+                det_fill(p, idx * 31 + j, 0.5); p.add_(1.0)
+            elif "layer_norm" in n:
+                det_fill(p, idx * 31 + j, 0.3)
+            elif p.dim() == 4:
+                fan_in = p.shape[1] * p.shape[2] * p.shape[3]
+                det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
+    x = mk_input((c["B"], c["C"], c["H"], c["W"]), idx, c["xscale"]).requires_grad_(True)
+
+    pre_ref = []
+    hooks = []
+    if c["kind"] in ("bspline", "cheby"):
+        for g in range(c["groups"]):
+            hooks.append(layer.layer_norm[g].register_forward_pre_hook(lambda m, a: pre_ref.append(a[0].detach().clone())))
+    y = layer(x)
+    for h in hooks:
+        h.remove()
+    g = mk_input(tuple(y.shape), idx + 500, 1.0)
+    y.backward(g)
+    ref = {"y": y.detach().clone(), "dx": x.grad.detach().clone()}
+    grads = {n: p.grad.detach().clone() for n, p in layer.named_parameters() if p.grad is not None}
+
+    # --- pin the oracle against the reference on this case
+    layer.zero_grad(set_to_none=True)
+    if hasattr(layer.layer_norm[0], "running_mean") and layer.layer_norm[0].running_mean is not None:
+        for ln in layer.layer_norm:
+            ln.reset_running_stats()
+    x2 = x.detach().clone().requires_grad_(True)
+    pre_or = []
+    y2 = oracle_forward(c, layer, x2, pre_or)
+    y2.backward(g)
+
+    def rel(a, b):
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+    errs = {"y": rel(y2.detach(), ref["y"]), "dx": rel(x2.grad, ref["dx"])}
+    for n, p in layer.named_parameters():
+        if n in grads:
+            errs["d" + n] = rel(p.grad, grads[n])
+    worst = max(errs.values())
+    assert worst < 2e-6, (c["name"], errs)
+
+    out = {"x": x.detach().numpy(), "g": g.numpy(), "y": ref["y"].numpy(), "dx": ref["dx"].numpy(),
+           "cfg": np.frombuffer(json.dumps(c).encode(), dtype=np.uint8)}
+    if pre_ref and c.get("save_z", True):
+        out["z"] = torch.cat(pre_ref, dim=1).numpy()
+    for n, t in layer.state_dict().items():
+        out["sd." + n] = t.detach().numpy()
+    for n, t in grads.items():
+        out["grad." + n] = t.numpy()
+    fn = os.path.join(HERE, f"{c['kind']}_{c['name']}.npz")
+    np.savez(fn, **out)
+    return worst, os.path.getsize(fn)
+
+
+# ---------------------------------------------------------------------------------- basis probes
+def basis_probes():
+    """Exact knots + basis tables at probe points."""
+    out = {}
+    xs = torch.cat([torch.linspace(-3.0, 3.0, 241), torch.tensor([-2.2, -1.0, -0.2, 0.0, 0.2, 1.0, 2.2, 2.1999998])])
+    for (G, S, rng) in [(5, 3, [-1, 1]), (3, 3, [-1, 1]), (8, 3, [-1, 1]), (5, 1, [-1, 1]), (5, 2, [-1, 1]), (5, 3, [-2, 2])]:
+        layer = KANConv2DLayer(1, 1, 1, spline_order=S, grid_size=G, grid_range=rng, base_activation=None)
+        captured = []
+        h = layer.spline_conv[0].register_forward_pre_hook(lambda m, a: captured.append(a[0].detach().clone()))
+        layer(xs.view(1, 1, 1, -1))
+        h.remove()
+        tab = captured[0].view(G + S, -1).t().contiguous()         # [n_x, G+S]
+        mine = O.bspline_basis(xs, O.bspline_knots(G, S, rng), S)
+        assert torch.equal(mine, tab), (G, S)
+        key = f"bspline_G{G}_S{S}_r{rng[1]}"
+        out[key + ".knots"] = layer.grid.numpy()
+        out[key + ".table"] = tab.numpy()
+    out["x"] = xs.numpy()
+    np.savez(os.path.join(HERE, "basis_probes.npz"), **out)
+
+
+# ---------------------------------------------------------------------------------- model level
+def import_ref_models():
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["models"] = pkg
+    return importlib.import_module("models.kan_vgg"), importlib.import_module("models.kan_alexnet")
+
+
+def model_fill(model):
+    with torch.no_grad():
+        for j, (n, p) in enumerate(model.named_parameters()):
+            if p.dim() == 4:
+                det_fill(p, j, (3.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+            elif p.dim() == 2:
+                det_fill(p, j, (1.0 / p.shape[1]) ** 0.5)
+            elif "prelus" in n:
+                p.fill_(0.25)
+            elif n.endswith("bias"):
+                det_fill(p, j, 0.05)
+            else:  # norm scale
+                det_fill(p, j, 0.2); p.add_(1.0)
+
+
+def run_model(name, model, x, t):
+    model.eval()   # Dropout(0.5) in the heads must be inert for a deterministic fixture; InstanceNorm is unaffected
+    model_fill(model)
+    logits = model(x)
+    loss = F.cross_entropy(logits, t)
+    loss.backward()
+    names = [n for n, _ in model.named_parameters()]
+    gn = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    ga = np.array([float(p.grad.abs().max()) for _, p in model.named_parameters()])
+    # a few explicit gradient slices (first 64 entries of every parameter's grad)
+    gs = np.stack([np.pad(p.grad.flatten()[:64].numpy(), (0, max(0, 64 - p.numel()))) for _, p in model.named_parameters()])
+    np.savez(os.path.join(HERE, f"model_{name}.npz"), x=x.numpy(), t=t.numpy(), logits=logits.detach().numpy(),
+             loss=np.array(float(loss.detach())), grad_norm=gn, grad_absmax=ga, grad_head=gs,
+             names=np.frombuffer(json.dumps(names).encode(), dtype=np.uint8))
+    print(f"model {name}: loss {float(loss):.6f} params {sum(p.numel() for p in model.parameters())}")
+
+
+def main():
+    total = 0
+    for i, c in enumerate(CASES):
+        worst, sz = run_case(i, c)
+        total += sz
+        print(f"{c['kind']:8s} {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+    basis_probes()
+    kv, ka = import_ref_models()
+    kv.cfgs["VGG11"] = O.VGG11_CFG
+    torch.manual_seed(0)
+    run_model("kan_vgg11", kv.vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear"),
+              mk_input((2, 3, 32, 32), 77, 1.0), torch.tensor([3, 7]))
+    torch.manual_seed(0)
+    run_model("cheby_alexnet", ka.alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4),
+              mk_input((1, 3, 224, 224), 78, 1.0), torch.tensor([5]))
+    print(f"total layer fixtures: {total / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,64 @@
+"""Shared helpers for parity tests: build this repo's layer / the oracle from a golden-case config."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+NORMS = {"in": nn.InstanceNorm2d, "bn": nn.BatchNorm2d}
+ACT_FN = {"gelu": F.gelu, "silu": F.silu, "none": None, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+DEFAULT_ACT = {"bspline": "gelu", "rbf": "silu"}
+
+# fp32 tolerances, max-normalised per tensor (the reference's own fp32-vs-fp64 noise is
+# <=3e-7 on y (2e-6 Cheby k11), <=5e-7 on dx, <=3.2e-6 on dW)
+TOL_Y, TOL_DX, TOL_DW = 1e-5, 1e-5, 5e-5
+
+
+def layer_kwargs(c):
+    kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
+    kw.update(c.get("norm_kwargs", {}))
+    if "norm" in c:
+        kw["norm_layer"] = NORMS[c["norm"]]
+    if c["kind"] == "bspline":
+        for key in ("grid_size", "spline_order", "grid_range"):
+            if key in c:
+                kw[key] = c[key]
+    elif c["kind"] == "rbf":
+        for key in ("grid_size", "grid_range"):
+            if key in c:
+                kw[key] = c[key]
+    elif "degree" in c:
+        kw["degree"] = c["degree"]
+    if c["kind"] != "cheby" and "act" in c:
+        kw["base_activation"] = ACTS[c["act"]]
+    return kw
+
+
+def build_layer(c):
+    import convkan_amd as K
+    cls = {"bspline": K.KANConv2DLayer, "rbf": K.FastKANConv2DLayer, "cheby": K.ChebyKANConv2DLayer}[c["kind"]]
+    return cls(c["C"], c["O"], **layer_kwargs(c))
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def oracle_forward(c, layer, x, pre=None):
+    """Oracle forward with `layer`'s parameters (any object exposing the reference's attribute names)."""
+    from oracle import kan_oracle as O
+    G = c["groups"]
+    sd = dict(layer.named_parameters())
+    norms = [layer.layer_norm[g] for g in range(G)]
+    geo = dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=G)
+    if c["kind"] == "bspline":
+        knots = O.bspline_knots(layer.grid_size, layer.spline_order, layer.grid_range).to(x.device)
+        return O.kan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"spline_conv.{g}.weight"] for g in range(G)],
+                            [sd[f"prelus.{g}.weight"] for g in range(G)], knots=knots, spline_order=layer.spline_order,
+                            act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "rbf":
+        centres, denom = O.rbf_grid(layer.grid_size, layer.grid_range)
+        return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"spline_conv.{g}.weight"] for g in range(G)],
+                                centres=centres.to(x.device), denom=denom, act=ACT_FN[c.get("act", "silu")], norm=norms, **geo)
+    return O.chebykan_conv2d(x, [sd[f"poly_conv.{g}.weight"] for g in range(G)], degree=layer.degree, norm=norms,
+                             pre_norm_out=pre, **geo)

@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec, forward + loss + backward, KAN-VGG11 (B-spline conv, grid 5, order 3, SiLU,
+InstanceNorm2d, Linear head), synthetic 3x32x32, batch 256 per GPU (BASELINE.json configs[2]; configs[3] for N>1).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = zero grads, forward, CrossEntropy loss, backward (+ bucketed RCCL all-reduce of the gradients for N>1);
+no optimizer step.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
+GFLOP_PER_IMAGE = 8.249            # dense algorithmic count fwd+bwd for KAN-VGG11 @32x32
+
+
+def build_model(device):
+    from convkan_amd.models import vggkan
+    torch.manual_seed(0)
+    return vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear").to(device).train()
+
+
+def one_step(model, x, t, reducer=None):
+    model.zero_grad(set_to_none=True)
+    loss = F.cross_entropy(model(x), t)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    return loss
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline(batch: int, iters: int):
+    """The oracle (CPU restatement of the reference op sequence, torch CPU ops) timed on this box's host cores."""
+    from oracle.kan_oracle import OracleKANVGG
+    threads = host_cores()
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = OracleKANVGG().train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(batch, 3, 32, 32, generator=g)
+    t = torch.randint(0, 10, (batch,), generator=g)
+    times = []
+    for i in range(iters + 1):
+        t0 = time.perf_counter()
+        m.zero_grad(set_to_none=True)
+        F.cross_entropy(m(x), t).backward()
+        times.append(time.perf_counter() - t0)
+    best = sum(times[1:]) / iters                      # first iteration is warm-up
+    return {"value": round(batch / best, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle KAN-VGG11 fwd+loss+bwd, batch {batch}, mean of {iters} iters after 1 warm-up, torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--bucket-mb", type=int, default=96)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm device"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
+
+    import convkan_amd
+    from convkan_amd import ops
+    convkan_amd.build_library()
+
+    model = build_model(device)
+    reducer = None
+    if world > 1:
+        from convkan_amd.parallel import BucketedGradReducer
+        for p in model.parameters():                               # identical replicas (same seed); make it explicit
+            dist.broadcast(p.data, 0)
+        reducer = BucketedGradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20)
+    g = torch.Generator(device=device).manual_seed(1 + rank)
+    x = torch.randn(args.batch, 3, 32, 32, device=device, generator=g)
+    t = torch.randint(0, 10, (args.batch,), device=device, generator=g)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(model, x, t, reducer)
+    barrier()
+    ops.PROFILE = []                                  # HIP events around every conv-kernel launch of the timed steps
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step(model, x, t, reducer)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if rank == 0:
+        print(f"[bench] {args.steps} steps in {elapsed:.3f}s on {world} GPU(s)", file=sys.stderr, flush=True)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        # ---- per-kernel roofline from the HIP events
+        fam = {}
+        for name, flops, e0, e1 in prof:
+            ms = e0.elapsed_time(e1)
+            f = fam.setdefault(name, [0, 0.0, 0.0])
+            f[0] += 1; f[1] += ms; f[2] += flops
+        kernels = {n: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
+                       "share_of_step": round(v[1] / (elapsed * 1e3), 3)} for n, v in fam.items()}
+        dom = max(fam, key=lambda n: fam[n][1])
+        ach = fam[dom][2] / (fam[dom][1] * 1e-3) / 1e12
+        all_t = sum(v[1] for v in fam.values())
+        all_f = sum(v[2] for v in fam.values())
+        ips = world * args.batch * args.steps / elapsed
+        out = {
+            "metric": "images/sec fwd+bwd KAN-VGG11 3x32x32 bs=256/GPU",
+            "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (randn images, randint labels; seeded random-init weights)",
+            "config": {"workload": "KAN-VGG11 (KANConv2DLayer x8, grid=5, order=3, SiLU, InstanceNorm2d+PReLU, Linear head), "
+                                   "3x32x32, fwd+CE loss+bwd, no optimizer step", "per_gpu_batch": args.batch,
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}" if world > 1 else "single",
+                       "loss": round(float(loss.detach()), 6)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": kernels[dom]["avg_ms"], "flops_per_launch": round(fam[dom][2] / fam[dom][0] / 1e9, 3),
+                         "all_conv_kernels_tflops": round(all_f / (all_t * 1e-3) / 1e12, 2),
+                         "conv_kernel_share_of_step": round(all_t / (elapsed * 1e3), 3),
+                         "end_to_end_frac": round(ips * GFLOP_PER_IMAGE / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "kernels": kernels},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
+            out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -29,8 +29,9 @@ class KanBasis(C.Structure):
 
 
 class KanPlan(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("P", "K", "Kpad", "Opad", "fwd_splits", "bwd_data_splits", "bwd_weight_splits")] + \
-               [(n, C.c_longlong) for n in ("packed_weight_bytes", "fwd_slab_elems", "bwd_data_slab_elems", "bwd_weight_slab_elems")]
+    _fields_ = [(n, C.c_int) for n in ("P", "K", "IPC", "KC", "Kpad", "Opad", "fwd_splits", "bwd_data_splits", "bwd_weight_splits")] + \
+               [(n, C.c_longlong) for n in ("packed_weight_bytes", "bwd_data_weight_bytes", "fwd_slab_elems", "bwd_data_slab_elems",
+                                            "bwd_weight_slab_elems")]
 
 
 # every symbol include/kanconv.h declares, with its argument types
@@ -40,7 +41,7 @@ SIGNATURES = {
     "kan_version": (C.c_char_p, []),
     "kan_last_error": (C.c_char_p, []),
     "kan_plan": (_I, [_GP, _BP, C.POINTER(KanPlan)]),
-    "kan_pack_weights": (_I, [_P, _P, _P, _GP, _BP, _P]),
+    "kan_pack_weights": (_I, [_P, _P, _P, _P, _GP, _BP, _P]),
     "kan_conv_fwd": (_I, [_P, _P, _P, _P, _GP, _BP, _P]),
     "kan_conv_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _GP, _BP, _P]),
     "kan_conv_bwd_weight": (_I, [_P, _P, _P, _P, _GP, _BP, _P]),

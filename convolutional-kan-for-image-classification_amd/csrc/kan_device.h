@@ -59,80 +59,63 @@ __device__ __forceinline__ float kan_act_grad(int act, float x) {
     }
 }
 
-// ---------------------------------------------------------------- B-spline (local de Boor)
-// Restates kan_layers.py:209-233 for the <= S+1 bases that are non-zero at x: find the knot
-// interval [g_i, g_{i+1}) holding x with the SAME fp32 knots and half-open comparisons as
-// the reference's order-0 indicator, then run the Cox-de Boor recurrence on that interval
-// only.  N[r] is basis j0 + r, j0 = i - S.  With DERIV, D[r] is its derivative
-//   S * ( N_{j,S-1}/(g_{j+S}-g_j) - N_{j+1,S-1}/(g_{j+S+1}-g_{j+1}) ),
-// which is what autograd of the reference recursion evaluates to (the indicator has zero
-// gradient).  `kn` is the knot table in LDS, nkn = n_basis + S + 1 knots.
-template <int S, bool DERIV>
-__device__ __forceinline__ bool bspline_local(float x, const float* kn, int nkn, float inv_h,
-                                              int& j0, float (&N)[4], float (&D)[4]) {
-    const int NI = nkn - 1;                      // number of knot intervals
+// ---------------------------------------------------------------- B-spline (uniform knots, closed form)
+// Restates kan_layers.py:209-233 for the <= S+1 bases that are non-zero at x.  The knot interval
+// [g_i, g_{i+1}) holding x is found with the SAME fp32 knots and half-open comparisons as the
+// reference's order-0 indicator.  The reference's knot vector is always torch.linspace (uniform,
+// kan_layers.py:184-190; the host side rejects anything else), on which every Cox-de Boor
+// denominator is k*h, so the recursion collapses to the cardinal B-spline pieces in
+// u = (x - g_i)/h:   S=1: [1-u, u]   S=2: [(1-u)^2, -2u^2+2u+1, u^2]/2
+//                    S=3: [(1-u)^3, 3u^3-6u^2+4, -3u^3+3u^2+3u+1, u^3]/6
+// (max |delta| vs the reference recursion 1.8e-7).  N[r] is basis j0 + r,
+// j0 = i - S.  With DERIV, N holds d/dx instead (the indicator has zero gradient, so this is
+// what autograd of the reference recursion evaluates to).  `kn`: knot table in LDS.
+template <bool DERIV>
+__device__ __forceinline__ bool bspline_uniform(int S, float x, const float* kn, int nkn, float inv_h,
+                                                int& j0, float (&N)[4]) {
+    const int NI = nkn - 1;                          // number of knot intervals
     if (!(x >= kn[0] && x < kn[NI])) return false;   // also rejects NaN, as the indicator does
     int i = (int)floorf((x - kn[0]) * inv_h);
     i = min(max(i, 0), NI - 1);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {             // settle on the reference's own comparisons
-        if (x < kn[i]) i = max(i - 1, 0);
-        else if (x >= kn[i + 1]) i = min(i + 1, NI - 1);
-    }
+    float gi = kn[i];
+    if (x < gi) { i = max(i - 1, 0); gi = kn[i]; }   // settle on the reference's own comparisons
+    else if (x >= kn[i + 1]) { i = min(i + 1, NI - 1); gi = kn[i]; }
     j0 = i - S;
-    float left[5], right[5];
-#pragma unroll
-    for (int j = 1; j <= S + 1; ++j) {
-        left[j]  = x - kn[min(max(i + 1 - j, 0), NI)];
-        right[j] = kn[min(max(i + j, 0), NI)] - x;
-    }
-    N[0] = 1.f; N[1] = 0.f; N[2] = 0.f; N[3] = 0.f;
-    float Nm[4] = {1.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 1; j <= S; ++j) {
-        if (DERIV && j == S) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Nm[q] = N[q];
+    const float u = fminf(fmaxf((x - gi) * inv_h, 0.f), 1.f);
+    const float v = 1.f - u;
+    N[0] = N[1] = N[2] = N[3] = 0.f;
+    if (!DERIV) {
+        if (S == 0) { N[0] = 1.f; }
+        else if (S == 1) { N[0] = v; N[1] = u; }
+        else if (S == 2) { N[0] = 0.5f * v * v; N[1] = 0.5f * (1.f + 2.f * u * v); N[2] = 0.5f * u * u; }
+        else {
+            const float u2 = u * u, u3 = u2 * u;
+            const float k6 = 1.f / 6.f;
+            N[0] = k6 * v * v * v;
+            N[1] = k6 * (3.f * u3 - 6.f * u2 + 4.f);
+            N[2] = k6 * (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f);
+            N[3] = k6 * u3;
         }
-        float saved = 0.f;
-#pragma unroll
-        for (int r = 0; r < j; ++r) {
-            float temp = N[r] / (right[r + 1] + left[j - r]);
-            N[r] = saved + right[r + 1] * temp;
-            saved = left[j - r] * temp;
-        }
-        N[j] = saved;
-    }
-    if (DERIV) {
-        D[0] = D[1] = D[2] = D[3] = 0.f;
-        if (S > 0) {
-#pragma unroll
-            for (int r = 0; r <= S; ++r) {
-                float a = 0.f, b = 0.f;
-                if (r >= 1) a = Nm[r - 1] / (right[r] + left[S - r + 1]);
-                if (r <= S - 1) b = Nm[r] / (right[r + 1] + left[S - r]);
-                D[r] = (float)S * (a - b);
-            }
+    } else {
+        if (S == 1) { N[0] = -inv_h; N[1] = inv_h; }
+        else if (S == 2) { N[0] = -v * inv_h; N[1] = (1.f - 2.f * u) * inv_h; N[2] = u * inv_h; }
+        else if (S == 3) {
+            const float u2 = u * u, hh = 0.5f * inv_h;
+            N[0] = -hh * v * v;
+            N[1] = hh * (3.f * u2 - 4.f * u);
+            N[2] = hh * (-3.f * u2 + 2.f * u + 1.f);
+            N[3] = hh * u2;
         }
     }
     return true;
 }
 
-template <bool DERIV>
-__device__ __forceinline__ bool bspline_dispatch(int S, float x, const float* kn, int nkn, float inv_h,
-                                                 int& j0, float (&N)[4], float (&D)[4]) {
-    switch (S) {
-        case 0:  return bspline_local<0, DERIV>(x, kn, nkn, inv_h, j0, N, D);
-        case 1:  return bspline_local<1, DERIV>(x, kn, nkn, inv_h, j0, N, D);
-        case 2:  return bspline_local<2, DERIV>(x, kn, nkn, inv_h, j0, N, D);
-        default: return bspline_local<3, DERIV>(x, kn, nkn, inv_h, j0, N, D);
-    }
-}
-
 // ---------------------------------------------------------------- plane expansion
 // DERIV == false: v[p] = plane p of (xa, xb);  DERIV == true: v[p] = d plane_p / d input.
 // xa feeds the base branch, xb feeds the basis (xa == xb except for FastKAN).
-template <bool DERIV>
+// KIND is a template parameter so that each kernel instantiation carries ONE basis family's code
+// (all families inlined at every staging site made the kernels thrash the instruction cache).
+template <int KIND, bool DERIV>
 __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs, float xa, float xb,
                                            float (&v)[KAN_PMAX]) {
 #pragma unroll
@@ -140,20 +123,19 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
     const int hb = bs.hb;
     if (hb) v[0] = DERIV ? kan_act_grad(bs.act, xa) : kan_act(bs.act, xa);
 
-    if (bs.kind == KAN_BASIS_BSPLINE) {
-        int j0; float N[4], D[4];
-        if (bspline_dispatch<DERIV>(bs.order, xb, tabs, bs.nb + bs.order + 1, bs.inv_h, j0, N, D)) {
+    if (KIND == KAN_BASIS_BSPLINE) {
+        int j0; float N[4];
+        if (bspline_uniform<DERIV>(bs.order, xb, tabs, bs.nb + bs.order + 1, bs.inv_h, j0, N)) {
 #pragma unroll
             for (int p = 0; p < KAN_PMAX; ++p) {
                 const int j = p - hb;                 // basis index of this plane
                 const int d = j - j0;                 // position inside the local support
                 float val = 0.f;
-                if (DERIV) { val = d == 0 ? D[0] : val; val = d == 1 ? D[1] : val; val = d == 2 ? D[2] : val; val = d == 3 ? D[3] : val; }
-                else       { val = d == 0 ? N[0] : val; val = d == 1 ? N[1] : val; val = d == 2 ? N[2] : val; val = d == 3 ? N[3] : val; }
+                val = d == 0 ? N[0] : val; val = d == 1 ? N[1] : val; val = d == 2 ? N[2] : val; val = d == 3 ? N[3] : val;
                 if (j >= 0 && j < bs.nb && d <= bs.order) v[p] = val;
             }
         }
-    } else if (bs.kind == KAN_BASIS_RBF) {
+    } else if (KIND == KAN_BASIS_RBF) {
         // utils/utils.py:33  exp(-((x - c)/d)^2)
         const float dn = bs.p0;
 #pragma unroll
@@ -166,21 +148,26 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
             }
         }
     } else {
-        // cheby_kan_layers.py:93-96  cos(k * acos(clamp(tanh x)))
+        // cheby_kan_layers.py:93-96  T_k = cos(k * acos(t)), t = clamp(tanh x, lo, hi), evaluated by the three-term
+        // recurrence T_k = 2 t T_{k-1} - T_{k-2} (max |delta| 9.8e-7 vs the reference for
+        // degree 4).  Gradient as autograd forms it: dT_k/dx = k sin(k th)/sin(th) * (1 - tanh^2 x) inside the clamp
+        // = k U_{k-1}(t) (1 - t0^2), zero where the clamp is active (clamp passes gradient on [lo, hi]).
         const float t0 = tanhf(xb);
         const float t = fminf(fmaxf(t0, bs.p0), bs.p1);
-        const float th = acosf(t);
-        float chain = 0.f;                            // d theta / d x  (clamp passes grad on [lo, hi])
-        if (DERIV) {
-            const bool inside = (t0 >= bs.p0) && (t0 <= bs.p1);
-            chain = inside ? -rsqrtf(1.0f - t * t) * (1.0f - t0 * t0) : 0.f;
-        }
+        const bool inside = (t0 >= bs.p0) && (t0 <= bs.p1);
+        const float chain = inside ? (1.0f - t0 * t0) : 0.f;
+        float Tm = 1.f, Tc = t;              // T_{k-1}, T_k   at k = 1
+        float Um = 0.f, Uc = 1.f;            // U_{k-2}, U_{k-1} at k = 1  (U_{-1} = 0, U_0 = 1)
 #pragma unroll
         for (int p = 0; p < KAN_PMAX; ++p) {
-            const int j = p - hb;
-            if (j >= 0 && j < bs.nb) {
-                const float kf = (float)j;
-                v[p] = DERIV ? (-sinf(kf * th) * kf) * chain : cosf(kf * th);
+            const int k = p - hb;
+            if (k >= 0 && k < bs.nb) {
+                if (k == 0) v[p] = DERIV ? 0.f : 1.f;
+                else {
+                    v[p] = DERIV ? (float)k * Uc * chain : Tc;
+                    const float Tn = 2.f * t * Tc - Tm; Tm = Tc; Tc = Tn;
+                    const float Un = 2.f * t * Uc - Um; Um = Uc; Uc = Un;
+                }
             }
         }
     }

@@ -24,7 +24,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int KC = 32;                      // GEMM-depth rows staged in LDS per step
 
 thread_local char g_err[512] = "";
 int fail(const char* fmt, const char* a = "") {
@@ -41,80 +40,165 @@ struct DevGeom {
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ============================================================================ pack / unpack
-// Reference weight layouts -> Wp[((c*T+tap)*P+p)][o].  A 32x32 tile goes through LDS so that both
-// the read (along the source's contiguous (channel,tap) axis) and the write (along o) coalesce.
-// src_kind 0: base weights [O][C][T]        -> plane 0
-// src_kind 1: basis weights [O][C*nb][T]    -> plane hb + q
-template <bool UNPACK>
-__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src_c, float* __restrict__ dst_c,
-                                              float* __restrict__ src_m, const float* __restrict__ wp_in, float* __restrict__ wp_out,
-                                              int O, int C, int T, int P, int hb, int nb, int src_kind, int Opad,
-                                              int n_slabs, long long slab_elems) {
+// Packed forward layout: the GEMM depth axis is cut into chunks of IPC "items" (item = (c, tap)), each item owning
+// P consecutive rows (its planes); a chunk is KC = even(IPC*P) rows, so that one LDS step of the forward kernel is
+// exactly IPC whole items:   k(item, p) = (item / IPC) * KC + (item % IPC) * P + p.
+// The weight-gradient kernel uses the same formula with IPC = 1, KC = P (flat, no padding).
+// src_kind 0: base weights [O][C][T] -> plane 0;   src_kind 1: basis weights [O][C*nb][T] -> plane hb + q.
+// A 32x32 tile goes through LDS so that both the read (along the source's contiguous (channel,tap) axis) and the
+// write (along o) coalesce.
+struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad; };
+
+__device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
+    int cq = j / q.T, tap = j - cq * q.T;
+    int c = src_kind == 0 ? cq : cq / q.nb;
+    int p = src_kind == 0 ? 0 : q.hb + (cq - c * q.nb);
+    int item = c * q.T + tap;
+    int chunk = item / q.IPC;
+    return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
+}
+
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, float* __restrict__ wp, PackGeo q, int src_kind) {
     __shared__ float tile[32][33];
-    const int J = src_kind == 0 ? C * T : C * nb * T;       // source row length
+    const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;       // source row length
     const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    auto kof = [&](int j) -> int {
-        int cq = j / T, tap = j - cq * T;
-        int c = src_kind == 0 ? cq : cq / nb;
-        int q = src_kind == 0 ? 0 : cq - c * nb;
-        int p = src_kind == 0 ? 0 : hb + q;
-        return (c * T + tap) * P + p;
-    };
-    if (!UNPACK) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int o = o0 + ty + 8 * i, j = j0 + tx;
-            tile[ty + 8 * i][tx] = (o < O && j < J) ? src_c[(size_t)o * J + j] : 0.f;
-        }
-        __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        int o = o0 + ty + 8 * i, j = j0 + tx;
+        tile[ty + 8 * i][tx] = (o < q.O && j < J) ? src[(size_t)o * J + j] : 0.f;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int j = j0 + ty + 8 * i, o = o0 + tx;
-            if (j < J && o < Opad) wp_out[(size_t)kof(j) * Opad + o] = tile[tx][ty + 8 * i];
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int j = j0 + ty + 8 * i, o = o0 + tx;
-            float s = 0.f;
-            if (j < J && o < O) {
-                size_t a = (size_t)kof(j) * Opad + o;
-                for (int sl = 0; sl < n_slabs; ++sl) s += wp_in[a + (size_t)sl * slab_elems];
-            }
-            tile[ty + 8 * i][tx] = s;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int o = o0 + ty + 8 * i, j = j0 + tx;
-            if (o < O && j < J) src_m[(size_t)o * J + j] = tile[tx][ty + 8 * i];
-        }
+    for (int i = 0; i < 4; ++i) {
+        int j = j0 + ty + 8 * i, o = o0 + tx;
+        if (j < J && o < q.Opad) wp[(size_t)pack_row(q, src_kind, j) * q.Opad + o] = tile[tx][ty + 8 * i];
     }
 }
 
+__global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, float* __restrict__ dst, PackGeo q, int src_kind,
+                                                int n_slabs, long long slab_elems) {
+    __shared__ float tile[32][33];
+    const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;
+    const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int j = j0 + ty + 8 * i, o = o0 + tx;
+        float s = 0.f;
+        if (j < J && o < q.O) {
+            size_t a = (size_t)pack_row(q, src_kind, j) * q.Opad + o;
+            for (int sl = 0; sl < n_slabs; ++sl) s += dwp[a + (size_t)sl * slab_elems];
+        }
+        tile[ty + 8 * i][tx] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int o = o0 + ty + 8 * i, j = j0 + tx;
+        if (o < q.O && j < J) dst[(size_t)o * J + j] = tile[tx][ty + 8 * i];
+    }
+}
+
+// Backward-data weight layout, derived from the forward one by a per-tap tiled transpose:
+//   wd[(tap * Opad32 + o)][ct * 128 + cl * P + p] = wp[k((c*T+tap), p)][o],   c = ct*CT + cl,  CT = 128 / P
+// i.e. the depth axis (tap, o) is the row, and the 128 columns of one channel tile are contiguous and 16-B aligned.
+// Columns >= CT*P of a tile and rows o >= O are zero.
+__global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__ wp, float* __restrict__ wd, PackGeo q,
+                                                       int CT, int n_ct, int Opad32) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int col0 = blockIdx.x * 32, o0 = blockIdx.y * 32;          // columns of wd / rows of wd within this tap
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ncol = n_ct * 128;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                   // read wp along o (contiguous)
+        int col = col0 + ty + 8 * i, o = o0 + tx;
+        float v = 0.f;
+        if (col < ncol) {
+            int ct = col >> 7, w = col & 127, cl = w / q.P, p = w - cl * q.P, c = ct * CT + cl;
+            if (cl < CT && c < q.C && o < q.O) {
+                int item = c * q.T + tap, chunk = item / q.IPC;
+                v = wp[(size_t)(chunk * q.KC + (item - chunk * q.IPC) * q.P + p) * q.Opad + o];
+            }
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                                   // write wd along the columns (contiguous)
+        int o = o0 + ty + 8 * i, col = col0 + tx;
+        if (o < Opad32 && col < ncol) wd[((size_t)tap * Opad32 + o) * ncol + col] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ============================================================================ staging helpers
+// Write the P planes of one (pixel, item) unit into an LDS column.  `col` points at row 0 of the unit, `ld` is the
+// row stride, rows outside [row_lo, row_hi) (relative to `col`) are skipped.  B-spline planes are sparse (<= S+1 of
+// n_basis non-zero): zero the column, then overwrite the live rows (same lane, in-order LDS => correct).
+template <int KIND>
+__device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab, bool inb, float xa, float xb,
+                                           float* col, int ld, int row_lo, int row_hi) {
+    const int P = bs.P, hb = bs.hb;
+    if (KIND == KAN_BASIS_BSPLINE) {
+        float base = 0.f, N[4]; int j0 = 0; bool ok = false;
+        if (inb) {
+            if (hb) base = kan_act(bs.act, xa);
+            ok = bspline_uniform<false>(bs.order, xb, sTab, bs.nb + bs.order + 1, bs.inv_h, j0, N);
+        }
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p)
+            if (p < P && p >= row_lo && p < row_hi) col[p * ld] = (p < hb) ? base : 0.f;
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + r, row = hb + j;
+                if (r <= bs.order && j >= 0 && j < bs.nb && row >= row_lo && row < row_hi) col[row * ld] = N[r];
+            }
+        }
+    } else {
+        float v[KAN_PMAX];
+        if (inb) kan_planes<KIND, false>(bs, sTab, xa, xb, v);
+        else {
+#pragma unroll
+            for (int p = 0; p < KAN_PMAX; ++p) v[p] = 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p)
+            if (p < P && p >= row_lo && p < row_hi) col[p * ld] = v[p];
+    }
+}
+
+constexpr int KCM = 36;                        // max rows per forward LDS step (KC <= KCM, IPC <= 8)
+
 // ============================================================================ forward
-// Workgroup tile: TO = WO*64 outputs x TP = WP*64 output pixels, one 64x64 wave tile per wave
-// (2x2 MFMA 32x32x2).  Per step: KC rows of Wp -> sW, the matching KC rows of E -> sE.
-template <int WO, int WP>
-__global__ __launch_bounds__(WO * WP * 64, 2) void k_conv_fwd(
+// Workgroup tile: TO = WO*64 outputs x TP = WP*64 output pixels, one 64x64 wave tile per wave (2x2 MFMA 32x32x2).
+// Software pipeline, one barrier per step: global loads of step s+1 are issued before the MFMAs of step s, their
+// expansion + LDS writes go to the other buffer after the MFMAs.
+template <int KIND, int WO, int WP, int KC>
+__global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
     const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp, float* __restrict__ z,
-    DevGeom g, DevBasis bs, int Opad, int n_chunks, int chunks_per_split, long long slab_elems) {
+    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems) {
     constexpr int TO = WO * 64, TP = WP * 64, NT = WO * WP * 64;
-    __shared__ float sW[KC * TO];
-    __shared__ float sE[KC * TP];
+    static_assert(KC <= KCM && KC % 2 == 0, "KC");
+    constexpr int IPP = NT / TP;                          // items handled per pass over the pixels
+    constexpr int UMAX = (8 + IPP - 1) / IPP;             // units per thread (IPC <= 8)
+    constexpr int WLD = (KCM * TO / 4 + NT - 1) / NT;     // float4 weight loads per thread
+    __shared__ __attribute__((aligned(16))) float sW[2 * KCM * TO];
+    __shared__ float sE[2 * KCM * TP];
     __shared__ float sTab[KAN_MAX_TABLE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w_o = wave / WP, w_p = wave % WP;
-    if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
-
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = bs.P;
-    const int Mtot = g.B * HoWo;
+    const int Mtot = g.B * HoWo, NI = g.C * T;
     const int px_tile0 = blockIdx.x * TP, o_tile0 = blockIdx.y * TO;
+    const int pxl = tid % TP, il0 = tid / TP;
 
-    // the pixel this thread expands for (fixed for the whole kernel: NT % TP == 0)
-    const int my_px = px_tile0 + (tid % TP);
+    if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
+    for (int i = tid; i < 2 * KCM * TP; i += NT) sE[i] = 0.f;           // pad rows stay zero for the whole kernel
+
+    const int my_px = px_tile0 + pxl;
     const bool pv = my_px < Mtot;
     int hi0, wi0; long long xoff;
     {
@@ -124,6 +208,55 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_conv_fwd(
         xoff = (long long)b * g.xbs;
     }
     const bool same_in = (x == xn);
+    const int wl_n = KC * TO / 4;                          // float4s per weight step
+
+    float xa[UMAX], xb[UMAX]; unsigned inb_mask = 0;
+    float4 wr[WLD];
+
+    auto issue = [&](int ch) {
+        inb_mask = 0;
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) {
+            const int il = il0 + u * IPP;
+            xa[u] = 0.f; xb[u] = 0.f;
+            if (il < IPC) {
+                const int item = __builtin_amdgcn_readfirstlane(ch * IPC + il);
+                const int c = item / T, tap = item - c * T;
+                const int r = tap / g.kw, t = tap - r * g.kw;
+                const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
+                const bool inb = pv && item < NI && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                if (inb) {
+                    long long idx = xoff + (long long)c * HW + hi * g.W + wi;
+                    xa[u] = x[idx];
+                    xb[u] = same_in ? xa[u] : xn[idx];
+                    inb_mask |= 1u << u;
+                }
+            }
+        }
+        const float* wsrc = wp + (size_t)ch * KC * Opad + o_tile0;
+#pragma unroll
+        for (int w = 0; w < WLD; ++w) {
+            const int i = tid + w * NT;
+            if (i < wl_n) {
+                int row = i / (TO / 4), c4 = i - row * (TO / 4);
+                wr[w] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * Opad + c4 * 4);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        float* dW = sW + buf * (KCM * TO);
+        float* dE = sE + buf * (KCM * TP);
+#pragma unroll
+        for (int w = 0; w < WLD; ++w) {
+            const int i = tid + w * NT;
+            if (i < wl_n) *reinterpret_cast<float4*>(dW + i * 4) = wr[w];
+        }
+#pragma unroll
+        for (int u = 0; u < UMAX; ++u) {
+            const int il = il0 + u * IPP;
+            if (il < IPC) stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, 0, P);
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -135,57 +268,29 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_conv_fwd(
 
     const int ch0 = blockIdx.z * chunks_per_split;
     const int ch1 = min(n_chunks, ch0 + chunks_per_split);
+    issue(ch0);
+    __syncthreads();                                       // sTab + zero fill visible
+    stage(0);
     __syncthreads();
 
+    const int ao = w_o * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
-        const int k0 = ch * KC;
-        // ---- weights: KC x TO floats, 16-B loads along o
-        for (int i = tid; i < KC * TO / 4; i += NT) {
-            int row = i / (TO / 4), c4 = i - row * (TO / 4);
-            float4 v = *reinterpret_cast<const float4*>(wp + (size_t)(k0 + row) * Opad + o_tile0 + c4 * 4);
-            *reinterpret_cast<float4*>(&sW[row * TO + c4 * 4]) = v;
-        }
-        // ---- expanded operand: items (c, tap) overlapping rows [k0, k0+KC)
-        const int item_first = k0 / P;
-        const int n_items = (k0 + KC - 1) / P - item_first + 1;
-        for (int il = tid / TP; il < n_items; il += NT / TP) {
-            const int item = __builtin_amdgcn_readfirstlane(item_first + il);   // wave-uniform
-            const int c = item / T, tap = item - c * T;
-            const int r = tap / g.kw, t = tap - r * g.kw;
-            const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
-            const bool inb = pv && c < g.C && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-            float v[KAN_PMAX];
-            if (inb) {
-                long long idx = xoff + (long long)c * HW + hi * g.W + wi;
-                float xa = x[idx];
-                float xb = same_in ? xa : xn[idx];
-                kan_planes<false>(bs, sTab, xa, xb, v);
-            } else {
-#pragma unroll
-                for (int p = 0; p < KAN_PMAX; ++p) v[p] = 0.f;
-            }
-            const int rbase = item * P - k0;
-#pragma unroll
-            for (int p = 0; p < KAN_PMAX; ++p) {
-                if (p < P) {
-                    int row = rbase + p;
-                    if ((unsigned)row < (unsigned)KC) sE[row * TP + (tid % TP)] = v[p];
-                }
-            }
-        }
-        __syncthreads();
-        // ---- MFMA: D[o][pixel] += W^T[o][k] * E[k][pixel]
-        const int ao = w_o * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
+        const int cur = (ch - ch0) & 1;
+        const bool more = ch + 1 < ch1;
+        if (more) issue(ch + 1);
+        const float* cW = sW + cur * (KCM * TO);
+        const float* cE = sE + cur * (KCM * TP);
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
             const int krow = 2 * kk + kh2;
-            float a0 = sW[krow * TO + ao], a1 = sW[krow * TO + ao + 32];
-            float b0 = sE[krow * TP + bp], b1 = sE[krow * TP + bp + 32];
+            float a0 = cW[krow * TO + ao], a1 = cW[krow * TO + ao + 32];
+            float b0 = cE[krow * TP + bp], b1 = cE[krow * TP + bp + 32];
             acc[0][0] = MFMA32(a0, b0, acc[0][0]);
             acc[0][1] = MFMA32(a0, b1, acc[0][1]);
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
         }
+        if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -209,37 +314,65 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_conv_fwd(
 }
 
 // ============================================================================ backward data
-// Tile: 128 rows = CT channels x P planes (flat c_local*P + p, CT = 128 / P) x 128 input pixels.
-// Depth chunks: (tap, 32 outputs).  Epilogue: G tile -> LDS, then dx = sum_p plane_p'(x) * G_p.
+// Tile: 128 rows = CT channels x P planes (flat cl*P + p, CT = 128 / P) x 128 input pixels.
+// Depth steps: (tap, 32 outputs); weights come from the wd layout (straight 32 x 128 copy), dz is gathered at the
+// output position each (input pixel, tap) pair feeds.  Same one-barrier pipeline as the forward kernel.
+// Epilogue: G tile -> LDS, then dx = sum_p plane_p'(x) * G_p.
+template <int KIND>
 __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
-    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp,
-    float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int Opad, int CT, int n_ob,
+    const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
+    float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CT, int n_ct, int n_ob, int Opad32,
     int n_chunks, int chunks_per_split, long long slab_elems) {
-    constexpr int TR = 128, TP = 128, LDW = TR + 1;
-    __shared__ float smem[TR * TP];                 // staging (sW: KC x LDW, sG: KC x TP) / epilogue (TR x TP)
-    __shared__ int sRowK[TR];
+    constexpr int TR = 128, TP = 128, KD = 32, NT = 256;
+    __shared__ __attribute__((aligned(16))) float smem[TR * TP];        // 2 x (sW 32x128 + sG 32x128) / epilogue 128x128
     __shared__ float sTab[KAN_MAX_TABLE];
-    float* sW = smem;
-    float* sG = smem + KC * LDW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w_r = wave >> 1, w_p = wave & 1;
-    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = bs.P;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, P = bs.P;
     const int Min = g.B * HW;
-    const int px_tile0 = blockIdx.x * TP, c_tile0 = blockIdx.y * CT;
+    const int px_tile0 = blockIdx.x * TP, ct = blockIdx.y, c_tile0 = ct * CT;
+    const int ncol = n_ct * 128;
+    const int pxl = tid & 127, ol0 = tid >> 7;
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
-    if (tid < TR) {
-        int cl = tid / P, p = tid - cl * P, c = c_tile0 + cl;
-        sRowK[tid] = (cl < CT && c < g.C) ? (c * T) * P + p : -1;
-    }
-    const int my_px = px_tile0 + (tid & 127);
+    const int my_px = px_tile0 + pxl;
     const bool pv = my_px < Min;
     int pb, ph_, pw_;
     {
         pb = my_px / HW; int hw = my_px - pb * HW;
         ph_ = hw / g.W; pw_ = hw - ph_ * g.W;
     }
+    const float* dzb = dz + (size_t)pb * g.ybs;
+
+    float gr[16]; float4 wr[4];
+    auto issue = [&](int ch) {
+        const int tap = ch / n_ob, o0 = (ch - tap * n_ob) * KD;
+        const int r = tap / g.kw, t = tap - r * g.kw;
+        const int hn = ph_ + g.ph - r * g.dh, wn = pw_ + g.pw - t * g.dw;
+        const int ho = hn / g.sh, wo = wn / g.sw;
+        const bool ok = pv && hn >= 0 && wn >= 0 && ho * g.sh == hn && wo * g.sw == wn && ho < g.Ho && wo < g.Wo;
+        const float* src = dzb + (size_t)ho * g.Wo + wo;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int o = o0 + ol0 + 2 * n;
+            gr[n] = (ok && o < g.O) ? src[(size_t)o * HoWo] : 0.f;
+        }
+        const float* wsrc = wd + ((size_t)tap * Opad32 + o0) * ncol + ct * 128;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int i = tid + w * NT, row = i >> 5, c4 = i & 31;
+            wr[w] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * ncol + c4 * 4);
+        }
+    };
+    auto stage = [&](int buf) {
+        float* dW = smem + buf * (2 * KD * 128);
+        float* dG = dW + KD * 128;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) *reinterpret_cast<float4*>(dW + (tid + w * NT) * 4) = wr[w];
+#pragma unroll
+        for (int n = 0; n < 16; ++n) dG[(ol0 + 2 * n) * TP + pxl] = gr[n];
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -251,45 +384,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
 
     const int ch0 = blockIdx.z * chunks_per_split;
     const int ch1 = min(n_chunks, ch0 + chunks_per_split);
+    issue(ch0);
+    stage(0);
     __syncthreads();
-
+    const int ar = w_r * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
-        const int tap = ch / n_ob, o0 = (ch - tap * n_ob) * KC;
-        const int r = tap / g.kw, t = tap - r * g.kw;
-        // ---- weights: sW[o_local][row], 32 consecutive o per (c,p) row = one 128-B segment
-        {
-            const int ol = tid & 31;
-            for (int row = tid >> 5; row < TR; row += 8) {
-                const int kb = sRowK[row];
-                float v = 0.f;
-                if (kb >= 0 && o0 + ol < g.O) v = wp[(size_t)(kb + tap * P) * Opad + o0 + ol];
-                sW[ol * LDW + row] = v;
-            }
-        }
-        // ---- dz gathered at the output position this (input pixel, tap) pair feeds
-        {
-            int hn = ph_ + g.ph - r * g.dh, wn = pw_ + g.pw - t * g.dw;
-            int ho = hn / g.sh, wo = wn / g.sw;
-            bool ok = pv && hn >= 0 && wn >= 0 && ho * g.sh == hn && wo * g.sw == wn && ho < g.Ho && wo < g.Wo;
-            const float* src = dz + (size_t)pb * g.ybs + (size_t)ho * g.Wo + wo;
-            for (int ol = tid >> 7; ol < KC; ol += 2) {
-                float v = 0.f;
-                if (ok && o0 + ol < g.O) v = src[(size_t)(o0 + ol) * HoWo];
-                sG[ol * TP + (tid & 127)] = v;
-            }
-        }
-        __syncthreads();
-        const int ar = w_r * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
+        const int cur = (ch - ch0) & 1;
+        const bool more = ch + 1 < ch1;
+        if (more) issue(ch + 1);
+        const float* cW = smem + cur * (2 * KD * 128);
+        const float* cG = cW + KD * 128;
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
+        for (int kk = 0; kk < KD / 2; ++kk) {
             const int krow = 2 * kk + kh2;
-            float a0 = sW[krow * LDW + ar], a1 = sW[krow * LDW + ar + 32];
-            float b0 = sG[krow * TP + bp], b1 = sG[krow * TP + bp + 32];
+            float a0 = cW[krow * 128 + ar], a1 = cW[krow * 128 + ar + 32];
+            float b0 = cG[krow * TP + bp], b1 = cG[krow * TP + bp + 32];
             acc[0][0] = MFMA32(a0, b0, acc[0][0]);
             acc[0][1] = MFMA32(a0, b1, acc[0][1]);
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
         }
+        if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -316,12 +431,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
         const float xa = x[idx];
         const float xb = same_in ? xa : xn[idx];
         float d[KAN_PMAX];
-        kan_planes<true>(bs, sTab, xa, xb, d);
+        kan_planes<KIND, true>(bs, sTab, xa, xb, d);
         float s_base = 0.f, s_bas = 0.f;
 #pragma unroll
         for (int p = 0; p < KAN_PMAX; ++p) {
             if (p < P) {
-                float gv = smem[(cl * P + p) * TP + (tid & 127)];
+                float gv = smem[(cl * P + p) * TP + pxl];
                 if (p < bs.hb) s_base += d[p] * gv; else s_bas += d[p] * gv;
             }
         }
@@ -331,16 +446,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
 }
 
 // ============================================================================ backward weight
-// Tile: TR = WR*64 rows of the packed K axis x TO = WC*64 outputs; depth chunks of 32 output pixels.
-template <int WR, int WC>
-__global__ __launch_bounds__(WR * WC * 64, 2) void k_conv_bwd_weight(
+// Tile: TR = WR*64 rows of the FLAT packed K axis (row = item*P + p) x TO = WC*64 outputs; depth steps of 32 output
+// pixels.  Same pipeline; the expanded operand is written [pixel][row] (pad 1) so that both the per-pixel writes
+// and the per-row MFMA reads are bank-conflict free.
+template <int KIND, int WR, int WC>
+__global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
-    DevGeom g, DevBasis bs, int Kpad, int Opad, int n_chunks, int chunks_per_split, long long slab_elems) {
-    constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, LDE = TR + 1, LDZ = TO + 1;
-    constexpr int MAXI = TR + 2;                    // items overlapping a row tile
-    __shared__ float sE[KC * LDE];
-    __shared__ float sZ[KC * LDZ];
-    __shared__ int sItem[MAXI];                     // c | r<<16 | t<<24, or -1
+    DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems) {
+    constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, LDE = TR + 1, LDZ = TO + 1, KPX = 32;
+    constexpr int IPP = NT / KPX;                    // items per pass
+    constexpr int UPF = 2;                           // units per thread with register prefetch (covers P >= 8 at TR = 128)
+    constexpr int ZL = TO * KPX / NT;                // dz loads per thread
+    constexpr int MAXI = TR + 2;
+    __shared__ float sE[2 * KPX * LDE];
+    __shared__ float sZ[2 * KPX * LDZ];
+    __shared__ int sItem[MAXI];                      // c | r<<16 | t<<24, or -1
     __shared__ float sTab[KAN_MAX_TABLE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -350,6 +470,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_conv_bwd_weight(
     const int k0 = blockIdx.x * TR, o_tile0 = blockIdx.y * TO;
     const int item_first = k0 / P;
     const int n_items = (k0 + TR - 1) / P - item_first + 1;
+    const int pl = tid & 31, il0 = tid >> 5;
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     for (int i = tid; i < n_items; i += NT) {
@@ -361,6 +482,66 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_conv_bwd_weight(
         sItem[i] = v;
     }
     const bool same_in = (x == xn);
+    __syncthreads();
+
+    float xa[UPF], xb[UPF], zr[ZL]; unsigned inb_mask = 0;
+    // per-step pixel decode (kept for the rare units beyond the prefetch window)
+    int s_b = 0, s_hi0 = 0, s_wi0 = 0; bool s_pv = false;
+
+    auto unit_addr = [&](int it, int b, int hi0, int wi0, bool pv, size_t& idx) -> bool {
+        const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
+        const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
+        idx = (size_t)b * g.xbs + (size_t)c * HW + (size_t)(hi * g.W + wi);
+        return pv && it >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+    };
+    auto issue = [&](int ch) {
+        const int px = ch * KPX + pl;
+        const bool pv = px < Mtot;
+        const int b = px / HoWo, hw = px - b * HoWo;
+        const int ho = hw / g.Wo, wo = hw - ho * g.Wo;
+        s_b = b; s_hi0 = ho * g.sh - g.ph; s_wi0 = wo * g.sw - g.pw; s_pv = pv;
+        inb_mask = 0;
+#pragma unroll
+        for (int u = 0; u < UPF; ++u) {
+            const int il = il0 + u * IPP;
+            xa[u] = 0.f; xb[u] = 0.f;
+            if (il < n_items) {
+                size_t idx;
+                if (unit_addr(sItem[il], b, s_hi0, s_wi0, pv, idx)) {
+                    xa[u] = x[idx];
+                    xb[u] = same_in ? xa[u] : xn[idx];
+                    inb_mask |= 1u << u;
+                }
+            }
+        }
+        const float* src = dz + (size_t)b * g.ybs + hw;
+#pragma unroll
+        for (int n = 0; n < ZL; ++n) {
+            const int o = o_tile0 + il0 + n * IPP;
+            zr[n] = (pv && o < g.O) ? src[(size_t)o * HoWo] : 0.f;
+        }
+    };
+    auto stage = [&](int buf) {
+        float* dE = sE + buf * (KPX * LDE) + pl * LDE;
+        float* dZ = sZ + buf * (KPX * LDZ) + pl * LDZ;
+#pragma unroll
+        for (int u = 0; u < UPF; ++u) {
+            const int il = il0 + u * IPP;
+            if (il < n_items) {
+                const int rbase = (item_first + il) * P - k0;
+                stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, -rbase, TR - rbase);
+            }
+        }
+        for (int il = il0 + UPF * IPP; il < n_items; il += IPP) {        // only for very small P (many items per tile)
+            size_t idx; float va = 0.f, vb = 0.f;
+            const bool inb = unit_addr(sItem[il], s_b, s_hi0, s_wi0, s_pv, idx);
+            if (inb) { va = x[idx]; vb = same_in ? va : xn[idx]; }
+            const int rbase = (item_first + il) * P - k0;
+            stage_unit<KIND>(bs, sTab, inb, va, vb, dE + rbase, 1, -rbase, TR - rbase);
+        }
+#pragma unroll
+        for (int n = 0; n < ZL; ++n) dZ[il0 + n * IPP] = zr[n];
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -372,60 +553,27 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_conv_bwd_weight(
 
     const int ch0 = blockIdx.z * chunks_per_split;
     const int ch1 = min(n_chunks, ch0 + chunks_per_split);
+    issue(ch0);
+    stage(0);
     __syncthreads();
-
+    const int ar = w_r * 64 + (lane & 31), bo = w_c * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
-        const int pl = tid & 31;
-        const int px = ch * KC + pl;
-        const bool pv = px < Mtot;
-        const int b = px / HoWo, hw = px - b * HoWo;
-        const int ho = hw / g.Wo, wo = hw - ho * g.Wo;
-        const int hi0 = ho * g.sh - g.ph, wi0 = wo * g.sw - g.pw;
-        // ---- expanded operand sE[pixel][row]
-        for (int il = tid >> 5; il < n_items; il += NT / 32) {
-            const int it = sItem[il];
-            const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
-            const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
-            const bool inb = pv && it >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-            float v[KAN_PMAX];
-            if (inb) {
-                size_t idx = (size_t)b * g.xbs + (size_t)c * HW + (size_t)(hi * g.W + wi);
-                float xa = x[idx];
-                float xb = same_in ? xa : xn[idx];
-                kan_planes<false>(bs, sTab, xa, xb, v);
-            } else {
+        const int cur = (ch - ch0) & 1;
+        const bool more = ch + 1 < ch1;
+        if (more) issue(ch + 1);
+        const float* cE = sE + cur * (KPX * LDE);
+        const float* cZ = sZ + cur * (KPX * LDZ);
 #pragma unroll
-                for (int p = 0; p < KAN_PMAX; ++p) v[p] = 0.f;
-            }
-            const int rbase = (item_first + il) * P - k0;
-#pragma unroll
-            for (int p = 0; p < KAN_PMAX; ++p) {
-                if (p < P) {
-                    int row = rbase + p;
-                    if ((unsigned)row < (unsigned)TR) sE[pl * LDE + row] = v[p];
-                }
-            }
-        }
-        // ---- dz tile sZ[pixel][o]
-        {
-            const float* src = dz + (size_t)b * g.ybs + hw;
-            for (int ol = tid >> 5; ol < TO; ol += NT / 32) {
-                int o = o_tile0 + ol;
-                sZ[pl * LDZ + ol] = (pv && o < g.O) ? src[(size_t)o * HoWo] : 0.f;
-            }
-        }
-        __syncthreads();
-        const int ar = w_r * 64 + (lane & 31), bo = w_c * 64 + (lane & 31), kh2 = lane >> 5;
-#pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
+        for (int kk = 0; kk < KPX / 2; ++kk) {
             const int krow = 2 * kk + kh2;
-            float a0 = sE[krow * LDE + ar], a1 = sE[krow * LDE + ar + 32];
-            float b0 = sZ[krow * LDZ + bo], b1 = sZ[krow * LDZ + bo + 32];
+            float a0 = cE[krow * LDE + ar], a1 = cE[krow * LDE + ar + 32];
+            float b0 = cZ[krow * LDZ + bo], b1 = cZ[krow * LDZ + bo + 32];
             acc[0][0] = MFMA32(a0, b0, acc[0][0]);
             acc[0][1] = MFMA32(a0, b1, acc[0][1]);
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
         }
+        if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -435,7 +583,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_conv_bwd_weight(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = k0 + w_r * 64 + mi * 32 + mfma_row(r, lane);
-            if (row >= Kpad) continue;
+            if (row >= Krows) continue;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int o = o_tile0 + w_c * 64 + ni * 32 + (lane & 31);
@@ -575,8 +723,16 @@ int check(const KanGeom* g, const KanBasis* b) {
     if ((long long)g->C * g->kh * g->kw * P >= (1ll << 30)) return fail("GEMM depth too large");
     if (b->kind == KAN_BASIS_BSPLINE) {
         if (b->order < 0 || b->order > 3) return fail("spline_order must be in 0..3");
-        if (b->n_basis + b->order + 1 > KAN_MAX_TABLE) return fail("too many knots");
+        const int nk = b->n_basis + b->order + 1;
+        if (nk > KAN_MAX_TABLE) return fail("too many knots");
         if (b->n_basis - b->order < 1) return fail("grid_size must be >= 1");
+        const float h = (b->table[nk - 1] - b->table[0]) / (float)(nk - 1);
+        if (!(h > 0.f)) return fail("knots must be increasing");
+        for (int i = 0; i < nk; ++i) {          // the closed-form basis assumes torch.linspace knots (kan_layers.py:184-190)
+            float d = b->table[i] - (b->table[0] + h * (float)i);
+            if (d < 0) d = -d;
+            if (d > 1e-4f * h) return fail("knots must be uniform (torch.linspace), as the reference always builds them");
+        }
     }
     if (b->kind == KAN_BASIS_RBF && (b->n_basis > KAN_MAX_TABLE || !(b->p0 != 0.f))) return fail("bad RBF parameters");
     return 0;
@@ -622,20 +778,21 @@ struct FwdCfg { int TO, TP, tiles_o, tiles_p, chunks, splits; };
 FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
     FwdCfg c;
     c.TO = (pl.Opad % 128 == 0) ? 128 : 64;
-    c.TP = c.TO == 128 ? 128 : 256;
+    c.TP = 128;
     c.tiles_o = pl.Opad / c.TO;
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
-    c.chunks = pl.Kpad / KC;
+    c.chunks = pl.Kpad / pl.KC;
     c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8);
     return c;
 }
-struct BdCfg { int CT, tiles_c, tiles_p, n_ob, chunks, splits; };
+struct BdCfg { int CT, tiles_c, tiles_p, n_ob, Opad32, chunks, splits; };
 BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     BdCfg c;
     c.CT = 128 / pl.P;
     c.tiles_c = ceil_div(g->C, c.CT);
     c.tiles_p = ceil_div((long long)g->B * g->H * g->W, 128);
-    c.n_ob = ceil_div(g->O, KC);
+    c.n_ob = ceil_div(g->O, 32);
+    c.Opad32 = c.n_ob * 32;
     c.chunks = g->kh * g->kw * c.n_ob;
     c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 8);
     return c;
@@ -645,27 +802,45 @@ BwCfg bw_cfg(const KanGeom* g, const KanPlan& pl) {
     BwCfg c;
     c.TO = (pl.Opad % 128 == 0) ? 128 : 64;
     c.TR = c.TO == 128 ? 128 : 256;
-    c.tiles_r = ceil_div(pl.Kpad, c.TR);
+    c.tiles_r = ceil_div(pl.K, c.TR);
     c.tiles_o = pl.Opad / c.TO;
-    c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, KC);
+    c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 32);
     c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 16);
     return c;
 }
 
 int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     if (int rc = check(g, b)) return rc;
+    const int T = g->kh * g->kw;
     pl->P = b->n_basis + (b->act != KAN_ACT_NONE);
-    pl->K = g->C * g->kh * g->kw * pl->P;
-    pl->Kpad = round_up(pl->K, KC);
+    pl->K = g->C * T * pl->P;
+    {   // LDS step of the forward kernel: KC in {32, 36} rows, IPC whole items; take the one wasting fewer rows
+        int i36 = 36 / pl->P, i32 = 32 / pl->P;
+        if (i36 > 8) i36 = 8;
+        if (i32 > 8) i32 = 8;
+        const bool use36 = (long long)i36 * pl->P * 32 > (long long)i32 * pl->P * 36;   // i36*P/36 > i32*P/32
+        pl->KC = use36 ? 36 : 32;
+        pl->IPC = use36 ? i36 : i32;
+    }
+    pl->Kpad = ceil_div(g->C * T, pl->IPC) * pl->KC;
     pl->Opad = round_up(g->O, 64);
     pl->packed_weight_bytes = (long long)pl->Kpad * pl->Opad * 4;
+    BdCfg bd = bd_cfg(g, *pl);
+    pl->bwd_data_weight_bytes = (long long)T * bd.Opad32 * bd.tiles_c * 128 * 4;
     pl->fwd_slab_elems = (long long)g->B * g->y_bstride;
     pl->bwd_data_slab_elems = (long long)g->B * g->x_bstride;
-    pl->bwd_weight_slab_elems = (long long)pl->Kpad * pl->Opad;
+    pl->bwd_weight_slab_elems = (long long)pl->K * pl->Opad;
     pl->fwd_splits = fwd_cfg(g, *pl).splits;
-    pl->bwd_data_splits = bd_cfg(g, *pl).splits;
+    pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = bw_cfg(g, *pl).splits;
     return 0;
+}
+
+PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool flat) {
+    PackGeo q;
+    q.O = g->O; q.C = g->C; q.T = g->kh * g->kw; q.P = pl.P; q.hb = b->act != KAN_ACT_NONE; q.nb = b->n_basis;
+    q.IPC = flat ? 1 : pl.IPC; q.KC = flat ? pl.P : pl.KC; q.Opad = pl.Opad;
+    return q;
 }
 
 template <int G>
@@ -689,7 +864,7 @@ int group_lanes(int HW) { int g = 4; while (g < 64 && g < HW) g <<= 1; return g;
 // ============================================================================ C ABI
 extern "C" {
 
-const char* kan_version(void) { return "kanconv 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+const char* kan_version(void) { return "kanconv 0.2 (gfx950, fp32 MFMA 32x32x2, pipelined)"; }
 const char* kan_last_error(void) { return g_err; }
 
 int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {
@@ -697,24 +872,32 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {
     return make_plan(geom, basis, plan);
 }
 
-int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, const KanGeom* g, const KanBasis* b, void* stream) {
+int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float* wd, const KanGeom* g, const KanBasis* b, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     const int hb = b->act != KAN_ACT_NONE;
     if ((hb && !w_base) || !w_basis || !wp) return fail("null weight pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int T = g->kh * g->kw;
-    if (pl.Kpad != pl.K) {   // zero the padding rows (columns >= O are written as zeros by the tiles)
-        if (hipMemsetAsync(wp + (size_t)pl.K * pl.Opad, 0, (size_t)(pl.Kpad - pl.K) * pl.Opad * 4, st) != hipSuccess) return fail("memset failed");
+    const int T = g->kh * g->kw, NI = g->C * T;
+    PackGeo q = pack_geo(g, b, pl, false);
+    // rows no source element maps to must be zero: pad rows of every chunk, and the missing items of the last chunk
+    if (pl.KC != pl.IPC * pl.P) {                       // (whole-buffer clear only for P that do not divide the step)
+        if (hipMemsetAsync(wp, 0, (size_t)pl.packed_weight_bytes, st) != hipSuccess) return fail("memset failed");
+    } else if (NI % pl.IPC != 0) {
+        size_t off = (size_t)(pl.Kpad - pl.KC) * pl.Opad;
+        if (hipMemsetAsync(wp + off, 0, (size_t)pl.KC * pl.Opad * 4, st) != hipSuccess) return fail("memset failed");
     }
     if (hb) {
         dim3 grid(ceil_div(g->C * T, 32), pl.Opad / 32);
-        hipLaunchKernelGGL((k_pack<false>), grid, dim3(256), 0, st, w_base, (float*)nullptr, (float*)nullptr, (const float*)nullptr, wp,
-                           g->O, g->C, T, pl.P, hb, b->n_basis, 0, pl.Opad, 0, 0ll);
+        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, wp, q, 0);
     }
     dim3 grid(ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32);
-    hipLaunchKernelGGL((k_pack<false>), grid, dim3(256), 0, st, w_basis, (float*)nullptr, (float*)nullptr, (const float*)nullptr, wp,
-                       g->O, g->C, T, pl.P, hb, b->n_basis, 1, pl.Opad, 0, 0ll);
+    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_basis, wp, q, 1);
+    if (wd) {
+        BdCfg c = bd_cfg(g, pl);
+        dim3 gd(c.tiles_c * 4, c.Opad32 / 32, T);
+        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CT, c.tiles_c, c.Opad32);
+    }
     return launch_ok("pack");
 }
 
@@ -725,14 +908,13 @@ int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const Ka
     if ((hb && !dw_base) || !dw_basis || !dwp) return fail("null weight-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
     const int T = g->kh * g->kw;
+    PackGeo q = pack_geo(g, b, pl, true);
     if (hb) {
         dim3 grid(ceil_div(g->C * T, 32), ceil_div(g->O, 32));
-        hipLaunchKernelGGL((k_pack<true>), grid, dim3(256), 0, st, (const float*)nullptr, (float*)nullptr, dw_base, dwp, (float*)nullptr,
-                           g->O, g->C, T, pl.P, hb, b->n_basis, 0, pl.Opad, pl.bwd_weight_splits, pl.bwd_weight_slab_elems);
+        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, q, 0, pl.bwd_weight_splits, pl.bwd_weight_slab_elems);
     }
     dim3 grid(ceil_div(g->C * b->n_basis * T, 32), ceil_div(g->O, 32));
-    hipLaunchKernelGGL((k_pack<true>), grid, dim3(256), 0, st, (const float*)nullptr, (float*)nullptr, dw_basis, dwp, (float*)nullptr,
-                       g->O, g->C, T, pl.P, hb, b->n_basis, 1, pl.Opad, pl.bwd_weight_splits, pl.bwd_weight_slab_elems);
+    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_basis, q, 1, pl.bwd_weight_splits, pl.bwd_weight_slab_elems);
     return launch_ok("unpack");
 }
 
@@ -746,28 +928,41 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_p, c.tiles_o, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
-    if (c.TO == 128)
-        hipLaunchKernelGGL((k_conv_fwd<2, 2>), grid, dim3(256), 0, st, x, xn, wp, z, dg, db, pl.Opad, c.chunks, cps, pl.fwd_slab_elems);
-    else
-        hipLaunchKernelGGL((k_conv_fwd<1, 4>), grid, dim3(256), 0, st, x, xn, wp, z, dg, db, pl.Opad, c.chunks, cps, pl.fwd_slab_elems);
+#define KAN_FWD(KIND, WO, WP, KCV) \
+    hipLaunchKernelGGL((k_conv_fwd<KIND, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems)
+#define KAN_FWD_KIND(KIND)                                                     \
+    do {                                                                       \
+        if (c.TO == 128 && pl.KC == 36) KAN_FWD(KIND, 2, 2, 36);               \
+        else if (c.TO == 128) KAN_FWD(KIND, 2, 2, 32);                         \
+        else if (pl.KC == 36) KAN_FWD(KIND, 1, 2, 36);                         \
+        else KAN_FWD(KIND, 1, 2, 32);                                          \
+    } while (0)
+    if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
+    else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
+    else KAN_FWD_KIND(KAN_BASIS_CHEBY);
+#undef KAN_FWD_KIND
+#undef KAN_FWD
     return launch_ok("conv_fwd");
 }
 
-int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wp, float* dx, float* dxn,
+int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn,
                       const KanGeom* g, const KanBasis* b, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
-    if (!dz || !x || !xn || !wp || !dx) return fail("null tensor pointer");
+    if (!dz || !x || !xn || !wd || !dx) return fail("null tensor pointer");
     if (!dxn && x != xn) return fail("dxn is required when xn != x");
-    if (pl.P > 128) return fail("too many planes");
     BdCfg c = bd_cfg(g, pl);
     DevGeom dg = dev_geom(g);
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_p, c.tiles_c, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
-    hipLaunchKernelGGL(k_conv_bwd_data, grid, dim3(256), 0, st, dz, x, xn, wp, dx, dxn, dg, db, pl.Opad, c.CT, c.n_ob, c.chunks, cps,
-                       pl.bwd_data_slab_elems);
+#define KAN_BD(KIND) \
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CT, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems)
+    if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
+    else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
+    else KAN_BD(KAN_BASIS_CHEBY);
+#undef KAN_BD
     return launch_ok("conv_bwd_data");
 }
 
@@ -781,12 +976,14 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_r, c.tiles_o, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
-    if (c.TO == 128)
-        hipLaunchKernelGGL((k_conv_bwd_weight<2, 2>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.Kpad, pl.Opad, c.chunks, cps,
-                           pl.bwd_weight_slab_elems);
-    else
-        hipLaunchKernelGGL((k_conv_bwd_weight<4, 1>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.Kpad, pl.Opad, c.chunks, cps,
-                           pl.bwd_weight_slab_elems);
+#define KAN_BW(KIND, WR, WC) \
+    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems)
+#define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
+    if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
+    else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
+    else KAN_BW_KIND(KAN_BASIS_CHEBY);
+#undef KAN_BW_KIND
+#undef KAN_BW
     return launch_ok("conv_bwd_weight");
 }
 

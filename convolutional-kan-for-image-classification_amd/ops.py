@@ -99,9 +99,36 @@ def _split_weights(spec: ConvSpec, weights: Sequence[torch.Tensor]):
     return [None] * G, list(weights[:G])
 
 
+# --------------------------------------------------------------------------------------- optional kernel timing
+# bench.py sets PROFILE to a list; each conv-kernel launch then appends (kernel name, algorithmic FLOPs, start, end)
+# with HIP events recorded on the launch stream (torch's current stream is the stream handed to the C ABI).
+PROFILE: Optional[list] = None
+
+
+def _launch(name: str, flops: float, t: torch.Tensor, fn) -> None:
+    if PROFILE is None:
+        L.check(fn(), name)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stream = torch.cuda.current_stream(t.device)
+    e0.record(stream)
+    L.check(fn(), name)
+    e1.record(stream)
+    PROFILE.append((name, flops, e0, e1))
+
+
+def _conv_flops(geom, plan) -> float:
+    """Dense algorithmic FLOPs of one conv-stage launch: 2*B*O*Ho*Wo*C*P*kh*kw."""
+    return 2.0 * geom.B * geom.O * geom.Ho * geom.Wo * geom.C * plan.P * geom.kh * geom.kw
+
+
+def _tile_tag(plan) -> str:
+    return "128" if plan.Opad % 128 == 0 else "64"
+
+
 # --------------------------------------------------------------------------------------- raw stages
-def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis):
-    """Returns (z_slabs [S,B,O,Ho,Wo], packed weights per group, geom, basis, plan)."""
+def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True):
+    """Returns (z_slabs [S,B,O,Ho,Wo], bwd-data weight layout per group (or None), geom, basis, plan)."""
     lib = L.load()
     B, Ct, H, W = x.shape
     G = spec.groups
@@ -113,11 +140,14 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis):
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
     packed = []
     for g in range(G):
-        wp = torch.empty(plan.Kpad * plan.Opad, device=x.device, dtype=torch.float32)
-        L.check(lib.kan_pack_weights(_ptr(w_base[g]), _ptr(w_basis[g]), _ptr(wp), C.byref(geom), C.byref(basis), st), "kan_pack_weights")
-        L.check(lib.kan_conv_fwd(_ptr(x, g * Cg * H * W), _ptr(xn if xn is not None else x, g * Cg * H * W), _ptr(wp),
-                                 _ptr(z, g * Og * Ho * Wo), C.byref(geom), C.byref(basis), st), "kan_conv_fwd")
-        packed.append(wp)
+        wp = torch.empty(plan.packed_weight_bytes // 4, device=x.device, dtype=torch.float32)
+        wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=x.device, dtype=torch.float32) if need_dgrad else None
+        L.check(lib.kan_pack_weights(_ptr(w_base[g]), _ptr(w_basis[g]), _ptr(wp), _ptr(wd), C.byref(geom), C.byref(basis), st),
+                "kan_pack_weights")
+        _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+                lambda: lib.kan_conv_fwd(_ptr(x, g * Cg * H * W), _ptr(xn if xn is not None else x, g * Cg * H * W), _ptr(wp),
+                                         _ptr(z, g * Og * Ho * Wo), C.byref(geom), C.byref(basis), st))
+        packed.append(wd)
     return z, packed, geom, basis, plan
 
 
@@ -139,8 +169,9 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     if need_w:
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
         for g in range(G):
-            L.check(lib.kan_conv_bwd_weight(_ptr(dz, g * Og * Ho * Wo), _ptr(x, g * Cg * H * W), _ptr(xs, g * Cg * H * W), _ptr(dwp),
-                                            C.byref(geom), C.byref(basis), st), "kan_conv_bwd_weight")
+            _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+                    lambda: lib.kan_conv_bwd_weight(_ptr(dz, g * Og * Ho * Wo), _ptr(x, g * Cg * H * W), _ptr(xs, g * Cg * H * W),
+                                                    _ptr(dwp), C.byref(geom), C.byref(basis), st))
             if spec.has_base:
                 dw_base[g] = torch.empty((Og, Cg, kh, kw), device=x.device, dtype=torch.float32)
             dw_basis[g] = torch.empty((Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
@@ -153,9 +184,10 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         dxns = torch.empty_like(dxs) if separate else None
         for g in range(G):
             off = g * Cg * H * W
-            L.check(lib.kan_conv_bwd_data(_ptr(dz, g * Og * Ho * Wo), _ptr(x, off), _ptr(xs, off), _ptr(packed[g]),
-                                          _ptr(dxs, off), _ptr(dxns, off) if separate else C.c_void_p(0),
-                                          C.byref(geom), C.byref(basis), st), "kan_conv_bwd_data")
+            _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
+                    lambda: lib.kan_conv_bwd_data(_ptr(dz, g * Og * Ho * Wo), _ptr(x, off), _ptr(xs, off), _ptr(packed[g]),
+                                                  _ptr(dxs, off), _ptr(dxns, off) if separate else C.c_void_p(0),
+                                                  C.byref(geom), C.byref(basis), st))
         dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
     return dx, dxn, dw_base, dw_basis
 
@@ -184,11 +216,12 @@ class _KanConv(torch.autograd.Function):
         xn = _require(xn, "xn") if xn is not None else None
         weights = [_require(w, "weight") for w in weights]
         w_base, w_basis = _split_weights(spec, weights)
+        need_dgrad = bool(ctx.needs_input_grad[1] or (xn is not None and ctx.needs_input_grad[2]))
         with torch.cuda.device(x.device):
-            z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis)
+            z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis, need_dgrad)
             z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
-        ctx.spec, ctx.has_xn, ctx.n_w = spec, xn is not None, len(weights)
-        ctx.save_for_backward(x, *( [xn] if xn is not None else [] ), *packed)
+        ctx.spec, ctx.has_xn, ctx.has_wd = spec, xn is not None, need_dgrad
+        ctx.save_for_backward(x, *([xn] if xn is not None else []), *(packed if need_dgrad else []))
         return z
 
     @staticmethod
@@ -196,7 +229,7 @@ class _KanConv(torch.autograd.Function):
         saved = ctx.saved_tensors
         x = saved[0]
         xn = saved[1] if ctx.has_xn else None
-        packed = saved[1 + int(ctx.has_xn):]
+        packed = saved[1 + int(ctx.has_xn):] if ctx.has_wd else [None] * ctx.spec.groups
         need_x, need_xn = ctx.needs_input_grad[1], ctx.has_xn and ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[3:])
         with torch.cuda.device(x.device):
@@ -222,8 +255,9 @@ class _KanConvInPrelu(torch.autograd.Function):
         prelus = rest[2 * G * int(use_affine):] if use_prelu else [None] * G
         if use_prelu and any(p.numel() != 1 for p in prelus):
             raise L.KanConvError("only scalar-slope PReLU (nn.PReLU()) is supported, as in kan_layers.py:182")
+        need_dgrad = bool(ctx.needs_input_grad[4])
         with torch.cuda.device(x.device):
-            zs, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis)
+            zs, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, need_dgrad)
             S, B, Ot, Ho, Wo = zs.shape
             Og, HW = Ot // G, Ho * Wo
             y = torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
@@ -236,8 +270,9 @@ class _KanConvInPrelu(torch.autograd.Function):
                                                    _ptr(prelus[g]), _ptr(y, off), _ptr(mean, g * B * Og), _ptr(rstd, g * B * Og),
                                                    B, Og, HW, Ot * HW, eps, st), "kan_instnorm_prelu_fwd")
         z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
-        ctx.spec, ctx.flags, ctx.n_params = spec, (use_affine, use_prelu), len(params)
-        ctx.save_for_backward(x, z, mean, rstd, *packed, *[t for t in list(gammas) + list(betas) + list(prelus) if t is not None])
+        ctx.spec, ctx.flags, ctx.has_wd = spec, (use_affine, use_prelu), need_dgrad
+        ctx.save_for_backward(x, z, mean, rstd, *(packed if need_dgrad else []),
+                              *[t for t in list(gammas) + list(betas) + list(prelus) if t is not None])
         return y
 
     @staticmethod
@@ -248,8 +283,9 @@ class _KanConvInPrelu(torch.autograd.Function):
         G = spec.groups
         saved = ctx.saved_tensors
         x, z, mean, rstd = saved[:4]
-        packed = saved[4:4 + G]
-        rest = list(saved[4 + G:])
+        nwd = G if ctx.has_wd else 0
+        packed = saved[4:4 + nwd] if ctx.has_wd else [None] * G
+        rest = list(saved[4 + nwd:])
         gammas = rest[:G] if use_affine else [None] * G
         betas = rest[G:2 * G] if use_affine else [None] * G
         prelus = rest[2 * G * int(use_affine):] if use_prelu else [None] * G

@@ -47,7 +47,8 @@ typedef struct KanGeom {
 /* Basis description.
  *   B-spline : n_basis = grid_size + spline_order, order = spline_order,
  *              table[0 .. n_basis+order] = the fp32 knots of torch.linspace
- *              (layers/kan_layers.py:184-190)
+ *              (layers/kan_layers.py:184-190); must be uniform, as the reference always
+ *              builds them (non-uniform knots are rejected)
  *   RBF      : n_basis = grid_size, table[0..n_basis-1] = centres, p0 = denominator
  *              (utils/utils.py:28-30)
  *   Chebyshev: n_basis = degree + 1, p0 / p1 = clamp bounds (-1+1e-7, 1-1e-7 as fp32)
@@ -63,15 +64,17 @@ typedef struct KanBasis {
 /* Launch plan for one geometry: split counts and workspace sizes (bytes). */
 typedef struct KanPlan {
     int P;                        /* planes per channel */
-    int K;                        /* GEMM depth of the forward conv: C*kh*kw*P */
-    int Kpad, Opad;               /* padded dims of the packed weight matrix [Kpad][Opad] */
+    int K;                        /* GEMM depth of the forward conv: C*kh*kw*P (= rows of the packed weight gradient) */
+    int IPC, KC;                  /* forward packing: IPC (c,tap) items per LDS step of KC = even(IPC*P) rows */
+    int Kpad, Opad;               /* dims of the packed weight matrix [Kpad][Opad], Kpad = ceil(C*kh*kw / IPC) * KC */
     int fwd_splits;               /* z is written as fwd_splits partial slabs */
     int bwd_data_splits;          /* dx is written as bwd_data_splits partial slabs */
     int bwd_weight_splits;        /* packed dW is written as bwd_weight_splits partial slabs */
     long long packed_weight_bytes;    /* Kpad*Opad*4 */
+    long long bwd_data_weight_bytes;  /* size of the bwd-data weight layout `wd` */
     long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */
     long long bwd_data_slab_elems;    /* B*x_bstride      : stride between dx slabs */
-    long long bwd_weight_slab_elems;  /* Kpad*Opad        : stride between dW slabs */
+    long long bwd_weight_slab_elems;  /* K*Opad           : stride between dW slabs */
 } KanPlan;
 
 const char* kan_version(void);
@@ -80,14 +83,17 @@ const char* kan_last_error(void);
 /* Fill `plan` for (geom, basis).  Pure host arithmetic, no device work. */
 int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
 
-/* Pack the reference-layout weights of one group into the GEMM layout used by all three
- * conv kernels:  wp[((c*T + tap)*P + p)][o],  T = kh*kw,  plane p = 0 is the base branch
- * (if any), planes hb.. are basis k = p - hb.  Replaces nothing in the reference (layout
- * only); sources are  base_conv[g].weight [O,C,kh,kw]  (kan_layers.py:159-166) and
+/* Pack the reference-layout weights of one group into the GEMM layouts of the kernels:
+ *   wp (forward):   wp[k(item,p)][o],  item = c*T + tap, T = kh*kw,
+ *                   k = (item / IPC)*KC + (item % IPC)*P + p;  plane p = 0 is the base branch
+ *                   (if any), planes hb.. are basis k = p - hb;  plan.packed_weight_bytes.
+ *   wd (bwd-data):  optional (NULL to skip), plan.bwd_data_weight_bytes:
+ *                   wd[tap*Opad32 + o][ct*128 + cl*P + p],  c = ct*(128/P) + cl.
+ * Replaces nothing in the reference (layout only); sources are  base_conv[g].weight [O,C,kh,kw]  (kan_layers.py:159-166) and
  * spline_conv[g].weight / poly_conv[g].weight [O,C*n_basis,kh,kw], channel c*n_basis+k
  * (kan_layers.py:170-177,237; fast_kan_layers.py:68-75,107; cheby_kan_layers.py:77-84,95).
  * `w_base` may be NULL iff basis->act == KAN_ACT_NONE. */
-int kan_pack_weights(const float* w_base, const float* w_basis, float* wp,
+int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float* wd,
                      const KanGeom* geom, const KanBasis* basis, void* stream);
 
 /* Fused forward:  z = act(x) (*) W_base + sum_k basis_k(xn) (*) W_basis[:, c*n+k]
@@ -107,12 +113,12 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z,
  *   dxn = sum_k basis_k'(xn) * dgrad(dz, W_basis)_k
  * If dxn == NULL the two are summed into dx (valid when xn == x).  Both are written as
  * plan.bwd_data_splits slabs of plan.bwd_data_slab_elems elements. */
-int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wp,
+int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wd,
                       float* dx, float* dxn,
                       const KanGeom* geom, const KanBasis* basis, void* stream);
 
-/* Gradient w.r.t. the packed weights: dwp[k][o] = sum_pixels expanded[k][pixel] * dz[o][pixel],
- * written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
+/* Gradient w.r.t. the weights in the FLAT packed layout dwp[(c*T+tap)*P + p][o]
+ * = sum_pixels expanded[k][pixel] * dz[o][pixel], written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
 int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,
                         const KanGeom* geom, const KanBasis* basis, void* stream);
 

@@ -27,6 +27,7 @@ def golden_cases(kind=None):
 def load_golden(name):
     d = dict(np.load(os.path.join(GOLDEN, name + ".npz")))
     d["cfg"] = json.loads(bytes(d["cfg"]).decode())
+    d["noise"] = json.loads(bytes(d["noise"]).decode()) if "noise" in d else {}
     return d
 
 

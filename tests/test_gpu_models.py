@@ -1,0 +1,70 @@
+"""Model-level GPU parity: KAN-VGG11 and ChebyKAN-AlexNet built from this repo's layers vs. the reference models'
+logits / loss / per-parameter gradient norms frozen in tests/golden/model_*.npz (parameters are set by the same
+machine-independent fill the generator used, in named_parameters order)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def det_fill(t, salt, scale):
+    i = torch.arange(t.numel(), dtype=torch.float64)
+    t.copy_((scale * torch.sin(i * 0.6180339887498949 * 7.0 + salt * 1.2345 + 0.1)).to(torch.float32).view_as(t))
+
+
+def model_fill(model):
+    with torch.no_grad():
+        for j, (n, p) in enumerate(model.named_parameters()):
+            if p.dim() == 4:
+                det_fill(p, j, (3.0 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+            elif p.dim() == 2:
+                det_fill(p, j, (1.0 / p.shape[1]) ** 0.5)
+            elif "prelus" in n:
+                p.fill_(0.25)
+            elif n.endswith("bias"):
+                det_fill(p, j, 0.05)
+            else:
+                det_fill(p, j, 0.2); p.add_(1.0)
+
+
+def run(name, model):
+    d = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
+    names = json.loads(bytes(d["names"]).decode())
+    assert names == [n for n, _ in model.named_parameters()]
+    model_fill(model)                       # on CPU, exactly as the generator did
+    model = model.cuda().eval()             # eval: head Dropout inert (the generator did the same)
+    x = torch.from_numpy(d["x"]).cuda()
+    t = torch.from_numpy(d["t"]).cuda()
+    logits = model(x)
+    loss = F.cross_entropy(logits, t)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(d["logits"])
+    err = float((logits.detach().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-4, f"logits err {err:.3e}"
+    assert abs(float(loss) - float(d["loss"])) <= 1e-4 * max(1.0, abs(float(d["loss"])))
+    gn = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
+    rel = np.abs(gn - d["grad_norm"]) / (d["grad_norm"] + 1e-30)
+    assert rel.max() <= 1e-3, f"grad-norm rel err {rel.max():.3e} at {names[int(rel.argmax())]}"
+    head = np.stack([np.pad(p.grad.flatten()[:64].cpu().numpy(), (0, max(0, 64 - p.numel()))) for _, p in model.named_parameters()])
+    herr = np.abs(head - d["grad_head"]).max(axis=1) / (d["grad_absmax"] + 1e-30)
+    assert herr.max() <= 1e-3, f"grad slice err {herr.max():.3e} at {names[int(herr.argmax())]}"
+
+
+def test_kan_vgg11(gpu_lib):
+    from convkan_amd.models import vggkan
+    torch.manual_seed(0)
+    run("kan_vgg11", vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear"))
+
+
+def test_cheby_alexnet(gpu_lib):
+    from convkan_amd.models import alexnet_kan
+    torch.manual_seed(0)
+    run("cheby_alexnet", alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4))

@@ -101,11 +101,12 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, f
 }
 
 // Backward-data weight layout, derived from the forward one by a per-tap tiled transpose:
-//   wd[(tap * Opad32 + o)][ct * 128 + cl * P + p] = wp[k((c*T+tap), p)][o],   c = ct*CT + cl,  CT = 128 / P
+//   wd[(tap * Opad16 + o)][ct * 128 + half * 64 + cl * P + p] = wp[k((c*T+tap), p)][o],
+//   c = (ct*2 + half) * CH + cl,  CH = 64 / P whole channels per 64-column half
 // i.e. the depth axis (tap, o) is the row, and the 128 columns of one channel tile are contiguous and 16-B aligned.
-// Columns >= CT*P of a tile and rows o >= O are zero.
+// Columns >= CH*P of a half and rows o >= O are zero.
 __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__ wp, float* __restrict__ wd, PackGeo q,
-                                                       int CT, int n_ct, int Opad32) {
+                                                       int CH, int n_ct, int Opad32) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
     const int col0 = blockIdx.x * 32, o0 = blockIdx.y * 32;          // columns of wd / rows of wd within this tap
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
         int col = col0 + ty + 8 * i, o = o0 + tx;
         float v = 0.f;
         if (col < ncol) {
-            int ct = col >> 7, w = col & 127, cl = w / q.P, p = w - cl * q.P, c = ct * CT + cl;
-            if (cl < CT && c < q.C && o < q.O) {
+            int hf = col >> 6, w = col & 63, cl = w / q.P, p = w - cl * q.P, c = hf * CH + cl;
+            if (cl < CH && c < q.C && o < q.O) {
                 int item = c * q.T + tap, chunk = item / q.IPC;
                 v = wp[(size_t)(chunk * q.KC + (item - chunk * q.IPC) * q.P + p) * q.Opad + o];
             }
@@ -169,23 +170,42 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
     }
 }
 
-constexpr int KCM = 36;                        // max rows per forward LDS step (KC <= KCM, IPC <= 8)
+// Occupancy is the lever on this chip for an exact-fp32 MFMA GEMM (measured: 2 -> 4 workgroups per CU took the
+// bwd-data kernel from 79 to 120 TFLOP/s): every kernel below is sized for FOUR 256-thread workgroups per CU,
+// i.e. <= 128 VGPRs and <= 40 KB of LDS, with 16-18 deep LDS steps, two LDS buffers and one barrier per step.
+// Masked gathers go through a raw buffer descriptor: an offset >= num_records returns 0 from the hardware bounds
+// check, so "out of image / out of tensor" costs neither a branch nor a second load (hipcc otherwise serialises
+// such loads behind s_waitcnt vmcnt(0)).  Offsets are 32-bit bytes: the host rejects tensors >= 2 GiB.
+#define KAN_OOB 0x80000000u
+typedef __amdgpu_buffer_rsrc_t kan_rsrc;
+__device__ __forceinline__ kan_rsrc make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(kan_rsrc r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+// Async 16-byte-per-lane copy global -> LDS (no VGPRs): lds_base is the WAVE-UNIFORM destination, lane i lands at
+// lds_base + 16*i; the source address is per lane.
+__device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
 
 // ============================================================================ forward
 // Workgroup tile: TO = WO*64 outputs x TP = WP*64 output pixels, one 64x64 wave tile per wave (2x2 MFMA 32x32x2).
-// Software pipeline, one barrier per step: global loads of step s+1 are issued before the MFMAs of step s, their
-// expansion + LDS writes go to the other buffer after the MFMAs.
+// Pipeline per step: [expand + write step s into buffer b] barrier [issue global loads of step s+1] [MFMAs on b].
 template <int KIND, int WO, int WP, int KC>
-__global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
+__global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp, float* __restrict__ z,
-    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems) {
-    constexpr int TO = WO * 64, TP = WP * 64, NT = WO * WP * 64;
-    static_assert(KC <= KCM && KC % 2 == 0, "KC");
+    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes) {
+    constexpr int TO = WO * 64, TP = WP * 64, NT = WO * WP * 64, NW = WO * WP;
     constexpr int IPP = NT / TP;                          // items handled per pass over the pixels
-    constexpr int UMAX = (8 + IPP - 1) / IPP;             // units per thread (IPC <= 8)
-    constexpr int WLD = (KCM * TO / 4 + NT - 1) / NT;     // float4 weight loads per thread
-    __shared__ __attribute__((aligned(16))) float sW[2 * KCM * TO];
-    __shared__ float sE[2 * KCM * TP];
+    constexpr int UMAX = 4 / IPP;                         // units per thread (IPC <= 4)
+    constexpr int RPI = 256 / TO;                         // weight rows per 1-KiB wave copy
+    constexpr int NQ = (KC + RPI - 1) / RPI;              // wave copies per weight step
+    static_assert(KC % 2 == 0, "KC");
+    __shared__ __attribute__((aligned(16))) float sW[2 * KC * TO];
+    __shared__ float sE[2 * KC * TP];
     __shared__ float sTab[KAN_MAX_TABLE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
     const int pxl = tid % TP, il0 = tid / TP;
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
-    for (int i = tid; i < 2 * KCM * TP; i += NT) sE[i] = 0.f;           // pad rows stay zero for the whole kernel
+    for (int i = tid; i < 2 * KC * TP; i += NT) sE[i] = 0.f;            // pad rows stay zero for the whole kernel
 
     const int my_px = px_tile0 + pxl;
     const bool pv = my_px < Mtot;
@@ -208,49 +228,39 @@ __global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
         xoff = (long long)b * g.xbs;
     }
     const bool same_in = (x == xn);
-    const int wl_n = KC * TO / 4;                          // float4s per weight step
+    const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(xn, x_bytes);
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
 
     float xa[UMAX], xb[UMAX]; unsigned inb_mask = 0;
-    float4 wr[WLD];
 
-    auto issue = [&](int ch) {
+    // issue(ch, buf): gather the x values of step ch into registers; start the async copy of its weight rows
+    // (KC rows x TO floats, a straight 2-D copy) into LDS buffer `buf`
+    auto issue = [&](int ch, int buf) {
         inb_mask = 0;
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;
-            xa[u] = 0.f; xb[u] = 0.f;
-            if (il < IPC) {
-                const int item = __builtin_amdgcn_readfirstlane(ch * IPC + il);
-                const int c = item / T, tap = item - c * T;
-                const int r = tap / g.kw, t = tap - r * g.kw;
-                const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
-                const bool inb = pv && item < NI && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-                if (inb) {
-                    long long idx = xoff + (long long)c * HW + hi * g.W + wi;
-                    xa[u] = x[idx];
-                    xb[u] = same_in ? xa[u] : xn[idx];
-                    inb_mask |= 1u << u;
-                }
-            }
+            const int item = __builtin_amdgcn_readfirstlane(ch * IPC + il);
+            const int c = item / T, tap = item - c * T;
+            const int r = tap / g.kw, t = tap - r * g.kw;
+            const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
+            const bool inb = il < IPC && pv && item < NI && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            const unsigned off = inb ? (unsigned)(xoff + (long long)c * HW + hi * g.W + wi) * 4u : KAN_OOB;
+            xa[u] = buf_load(x_rs, off);
+            xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
+            inb_mask |= (inb ? 1u : 0u) << u;
         }
         const float* wsrc = wp + (size_t)ch * KC * Opad + o_tile0;
+        float* dW = sW + buf * (KC * TO);
 #pragma unroll
-        for (int w = 0; w < WLD; ++w) {
-            const int i = tid + w * NT;
-            if (i < wl_n) {
-                int row = i / (TO / 4), c4 = i - row * (TO / 4);
-                wr[w] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * Opad + c4 * 4);
-            }
+        for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
+            const int q = j * NW + wv;                     // 1-KiB block index inside the weight step (wave-uniform)
+            const int row = q * RPI + lane / (TO / 4), c4 = lane % (TO / 4);
+            if (q < NQ && row < KC) glds16(wsrc + (size_t)row * Opad + c4 * 4, dW + q * 256);
         }
     };
     auto stage = [&](int buf) {
-        float* dW = sW + buf * (KCM * TO);
-        float* dE = sE + buf * (KCM * TP);
-#pragma unroll
-        for (int w = 0; w < WLD; ++w) {
-            const int i = tid + w * NT;
-            if (i < wl_n) *reinterpret_cast<float4*>(dW + i * 4) = wr[w];
-        }
+        float* dE = sE + buf * (KC * TP);
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;
@@ -268,18 +278,17 @@ __global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
 
     const int ch0 = blockIdx.z * chunks_per_split;
     const int ch1 = min(n_chunks, ch0 + chunks_per_split);
-    issue(ch0);
+    issue(ch0, 0);
     __syncthreads();                                       // sTab + zero fill visible
-    stage(0);
-    __syncthreads();
 
     const int ao = w_o * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
         const int cur = (ch - ch0) & 1;
-        const bool more = ch + 1 < ch1;
-        if (more) issue(ch + 1);
-        const float* cW = sW + cur * (KCM * TO);
-        const float* cE = sE + cur * (KCM * TP);
+        stage(cur);
+        __syncthreads();                                   // (drains the async weight copy of this step: vmcnt(0))
+        if (ch + 1 < ch1) issue(ch + 1, cur ^ 1);
+        const float* cW = sW + cur * (KC * TO);
+        const float* cE = sE + cur * (KC * TP);
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) {
             const int krow = 2 * kk + kh2;
@@ -290,8 +299,6 @@ __global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
         }
-        if (more) stage(cur ^ 1);
-        __syncthreads();
     }
 
     // ---- store: column (lane) = pixel => coalesced along the plane
@@ -314,24 +321,24 @@ __global__ __launch_bounds__(WO * WP * 64, WO) void k_conv_fwd(
 }
 
 // ============================================================================ backward data
-// Tile: 128 rows = CT channels x P planes (flat cl*P + p, CT = 128 / P) x 128 input pixels.
-// Depth steps: (tap, 32 outputs); weights come from the wd layout (straight 32 x 128 copy), dz is gathered at the
-// output position each (input pixel, tap) pair feeds.  Same one-barrier pipeline as the forward kernel.
-// Epilogue: G tile -> LDS, then dx = sum_p plane_p'(x) * G_p.
+// Tile: 128 rows = two halves of 64 rows, each holding CH = 64 / P whole channels x P planes (flat cl*P + p, rest
+// zero), x 128 input pixels.  Depth steps: (tap, 16 outputs); weights come from the wd layout (straight 16 x 128
+// copy), dz is gathered at the output position each (input pixel, tap) pair feeds.
+// Epilogue, one half at a time (32 KB of LDS): G half-tile -> LDS, then dx = sum_p plane_p'(x) * G_p.
 template <int KIND>
-__global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
+__global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
-    float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CT, int n_ct, int n_ob, int Opad32,
-    int n_chunks, int chunks_per_split, long long slab_elems) {
-    constexpr int TR = 128, TP = 128, KD = 32, NT = 256;
-    __shared__ __attribute__((aligned(16))) float smem[TR * TP];        // 2 x (sW 32x128 + sG 32x128) / epilogue 128x128
+    float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CH, int n_ct, int n_ob, int Opad16,
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes) {
+    constexpr int TP = 128, KD = 16, NT = 256;
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * KD * 128];   // 2 x (sW 16x128 + sG 16x128) = 32 KB; epilogue 64x128
     __shared__ float sTab[KAN_MAX_TABLE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w_r = wave >> 1, w_p = wave & 1;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, P = bs.P;
     const int Min = g.B * HW;
-    const int px_tile0 = blockIdx.x * TP, ct = blockIdx.y, c_tile0 = ct * CT;
+    const int px_tile0 = blockIdx.x * TP, ct = blockIdx.y;
     const int ncol = n_ct * 128;
     const int pxl = tid & 127, ol0 = tid >> 7;
 
@@ -343,35 +350,36 @@ __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
         pb = my_px / HW; int hw = my_px - pb * HW;
         ph_ = hw / g.W; pw_ = hw - ph_ * g.W;
     }
-    const float* dzb = dz + (size_t)pb * g.ybs;
+    const kan_rsrc dz_rs = make_rsrc(dz, dz_bytes);
+    const unsigned dz_img = (unsigned)pb * (unsigned)g.ybs;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
 
-    float gr[16]; float4 wr[4];
-    auto issue = [&](int ch) {
+    float gr[8];
+    // issue(ch, buf): gather dz of step ch into registers; start the async copy of its weight rows into LDS buffer `buf`
+    auto issue = [&](int ch, int buf) {
         const int tap = ch / n_ob, o0 = (ch - tap * n_ob) * KD;
         const int r = tap / g.kw, t = tap - r * g.kw;
         const int hn = ph_ + g.ph - r * g.dh, wn = pw_ + g.pw - t * g.dw;
         const int ho = hn / g.sh, wo = wn / g.sw;
         const bool ok = pv && hn >= 0 && wn >= 0 && ho * g.sh == hn && wo * g.sw == wn && ho < g.Ho && wo < g.Wo;
-        const float* src = dzb + (size_t)ho * g.Wo + wo;
+        const unsigned base = ok ? (dz_img + (unsigned)(ho * g.Wo + wo)) * 4u : KAN_OOB;
 #pragma unroll
-        for (int n = 0; n < 16; ++n) {
+        for (int n = 0; n < 8; ++n) {
             const int o = o0 + ol0 + 2 * n;
-            gr[n] = (ok && o < g.O) ? src[(size_t)o * HoWo] : 0.f;
+            gr[n] = buf_load(dz_rs, o < g.O ? base + (unsigned)o * (unsigned)HoWo * 4u : KAN_OOB);
         }
-        const float* wsrc = wd + ((size_t)tap * Opad32 + o0) * ncol + ct * 128;
+        const float* wsrc = wd + ((size_t)tap * Opad16 + o0) * ncol + ct * 128;
+        float* dW = smem + buf * (2 * KD * 128);
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int i = tid + w * NT, row = i >> 5, c4 = i & 31;
-            wr[w] = *reinterpret_cast<const float4*>(wsrc + (size_t)row * ncol + c4 * 4);
+        for (int j = 0; j < 2; ++j) {                      // 16 rows x 512 B = 8 wave-instructions of 1 KiB
+            const int blk = j * 4 + wv, row = blk * 2 + (lane >> 5), c4 = lane & 31;
+            glds16(wsrc + (size_t)row * ncol + c4 * 4, dW + blk * 256);
         }
     };
     auto stage = [&](int buf) {
-        float* dW = smem + buf * (2 * KD * 128);
-        float* dG = dW + KD * 128;
+        float* dG = smem + buf * (2 * KD * 128) + KD * 128;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) *reinterpret_cast<float4*>(dW + (tid + w * NT) * 4) = wr[w];
-#pragma unroll
-        for (int n = 0; n < 16; ++n) dG[(ol0 + 2 * n) * TP + pxl] = gr[n];
+        for (int n = 0; n < 8; ++n) dG[(ol0 + 2 * n) * TP + pxl] = gr[n];
     };
 
     f32x16 acc[2][2];
@@ -384,14 +392,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
 
     const int ch0 = blockIdx.z * chunks_per_split;
     const int ch1 = min(n_chunks, ch0 + chunks_per_split);
-    issue(ch0);
-    stage(0);
-    __syncthreads();
+    issue(ch0, 0);
     const int ar = w_r * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
         const int cur = (ch - ch0) & 1;
-        const bool more = ch + 1 < ch1;
-        if (more) issue(ch + 1);
+        stage(cur);
+        __syncthreads();                                   // (drains the async weight copy of this step: vmcnt(0))
+        if (ch + 1 < ch1) issue(ch + 1, cur ^ 1);
         const float* cW = smem + cur * (2 * KD * 128);
         const float* cG = cW + KD * 128;
 #pragma unroll
@@ -404,58 +411,63 @@ __global__ __launch_bounds__(256, 2) void k_conv_bwd_data(
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
         }
-        if (more) stage(cur ^ 1);
-        __syncthreads();
     }
 
-    // ---- epilogue: G tile to LDS, contract the P planes of each channel with plane'(x)
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = w_r * 64 + mi * 32 + mfma_row(r, lane);
-                int col = w_p * 64 + ni * 32 + (lane & 31);
-                smem[row * TP + col] = acc[mi][ni][r];
-            }
-    __syncthreads();
+    // ---- epilogue: per 64-row half, G -> LDS, contract the P planes of each channel with plane'(x)
     const bool same_in = (x == xn);
     const bool split_out = (dxn != nullptr);
     float* dxs = dx + (size_t)blockIdx.z * slab_elems;
     float* dxns = split_out ? dxn + (size_t)blockIdx.z * slab_elems : nullptr;
-    for (int cl = tid >> 7; cl < CT; cl += 2) {
-        const int c = c_tile0 + cl;
-        if (c >= g.C || !pv) continue;
-        const size_t idx = (size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_);
-        const float xa = x[idx];
-        const float xb = same_in ? xa : xn[idx];
-        float d[KAN_PMAX];
-        kan_planes<KIND, true>(bs, sTab, xa, xb, d);
-        float s_base = 0.f, s_bas = 0.f;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();                                   // previous readers of smem are done
+        if (w_r == half) {
 #pragma unroll
-        for (int p = 0; p < KAN_PMAX; ++p) {
-            if (p < P) {
-                float gv = smem[(cl * P + p) * TP + pxl];
-                if (p < bs.hb) s_base += d[p] * gv; else s_bas += d[p] * gv;
-            }
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = mi * 32 + mfma_row(r, lane);
+                        int col = w_p * 64 + ni * 32 + (lane & 31);
+                        smem[row * TP + col] = acc[mi][ni][r];
+                    }
         }
-        if (split_out) { dxs[idx] = s_base; dxns[idx] = s_bas; }
-        else dxs[idx] = s_base + s_bas;
+        __syncthreads();
+        for (int cl = tid >> 7; cl < CH; cl += 2) {
+            const int c = (ct * 2 + half) * CH + cl;
+            if (c >= g.C || !pv) continue;
+            const size_t idx = (size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_);
+            const float xa = x[idx];
+            const float xb = same_in ? xa : xn[idx];
+            float d[KAN_PMAX];
+            kan_planes<KIND, true>(bs, sTab, xa, xb, d);
+            float s_base = 0.f, s_bas = 0.f;
+#pragma unroll
+            for (int p = 0; p < KAN_PMAX; ++p) {
+                if (p < P) {
+                    float gv = smem[(cl * P + p) * TP + pxl];
+                    if (p < bs.hb) s_base += d[p] * gv; else s_bas += d[p] * gv;
+                }
+            }
+            if (split_out) { dxs[idx] = s_base; dxns[idx] = s_bas; }
+            else dxs[idx] = s_base + s_bas;
+        }
     }
 }
 
 // ============================================================================ backward weight
-// Tile: TR = WR*64 rows of the FLAT packed K axis (row = item*P + p) x TO = WC*64 outputs; depth steps of 32 output
-// pixels.  Same pipeline; the expanded operand is written [pixel][row] (pad 1) so that both the per-pixel writes
-// and the per-row MFMA reads are bank-conflict free.
+// Tile: TR = WR*64 rows of the FLAT packed K axis (row = item*P + p) x TO = WC*64 outputs; depth steps of 16 output
+// pixels.  The expanded operand is written [pixel][row] (pad 1) so that both the per-pixel writes and the per-row
+// MFMA reads are bank-conflict free (2-way at worst on the writes, which ds_write_b32 absorbs).
 template <int KIND, int WR, int WC>
-__global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
+__global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
-    DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems) {
-    constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, LDE = TR + 1, LDZ = TO + 1, KPX = 32;
-    constexpr int IPP = NT / KPX;                    // items per pass
-    constexpr int UPF = 2;                           // units per thread with register prefetch (covers P >= 8 at TR = 128)
+    DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems,
+    unsigned x_bytes, unsigned dz_bytes) {
+    constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, LDE = TR + 1, LDZ = TO + 1, KPX = 16;
+    constexpr int IPP = NT / KPX;                    // items per pass (16)
+    constexpr int UPF = TR / 128;                    // units per thread with register prefetch (covers P >= 8)
     constexpr int ZL = TO * KPX / NT;                // dz loads per thread
     constexpr int MAXI = TR + 2;
     __shared__ float sE[2 * KPX * LDE];
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
     const int k0 = blockIdx.x * TR, o_tile0 = blockIdx.y * TO;
     const int item_first = k0 / P;
     const int n_items = (k0 + TR - 1) / P - item_first + 1;
-    const int pl = tid & 31, il0 = tid >> 5;
+    const int pl = tid & (KPX - 1), il0 = tid / KPX;
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     for (int i = tid; i < n_items; i += NT) {
@@ -485,8 +497,8 @@ __global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
     __syncthreads();
 
     float xa[UPF], xb[UPF], zr[ZL]; unsigned inb_mask = 0;
-    // per-step pixel decode (kept for the rare units beyond the prefetch window)
-    int s_b = 0, s_hi0 = 0, s_wi0 = 0; bool s_pv = false;
+    int s_b = 0, s_hi0 = 0, s_wi0 = 0; bool s_pv = false;    // pixel decode of the staged step (for units beyond UPF)
+    const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(xn, x_bytes), dz_rs = make_rsrc(dz, dz_bytes);
 
     auto unit_addr = [&](int it, int b, int hi0, int wi0, bool pv, size_t& idx) -> bool {
         const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
@@ -504,21 +516,18 @@ __global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
 #pragma unroll
         for (int u = 0; u < UPF; ++u) {
             const int il = il0 + u * IPP;
-            xa[u] = 0.f; xb[u] = 0.f;
-            if (il < n_items) {
-                size_t idx;
-                if (unit_addr(sItem[il], b, s_hi0, s_wi0, pv, idx)) {
-                    xa[u] = x[idx];
-                    xb[u] = same_in ? xa[u] : xn[idx];
-                    inb_mask |= 1u << u;
-                }
-            }
+            size_t idx;
+            const bool inb = il < n_items && unit_addr(sItem[min(il, MAXI - 1)], b, s_hi0, s_wi0, pv, idx);
+            const unsigned off = inb ? (unsigned)idx * 4u : KAN_OOB;
+            xa[u] = buf_load(x_rs, off);
+            xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
+            inb_mask |= (inb ? 1u : 0u) << u;
         }
-        const float* src = dz + (size_t)b * g.ybs + hw;
+        const unsigned zbase = pv ? ((unsigned)b * (unsigned)g.ybs + (unsigned)hw) * 4u : KAN_OOB;
 #pragma unroll
         for (int n = 0; n < ZL; ++n) {
             const int o = o_tile0 + il0 + n * IPP;
-            zr[n] = (pv && o < g.O) ? src[(size_t)o * HoWo] : 0.f;
+            zr[n] = buf_load(dz_rs, o < g.O ? zbase + (unsigned)o * (unsigned)HoWo * 4u : KAN_OOB);
         }
     };
     auto stage = [&](int buf) {
@@ -532,7 +541,8 @@ __global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
                 stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, -rbase, TR - rbase);
             }
         }
-        for (int il = il0 + UPF * IPP; il < n_items; il += IPP) {        // only for very small P (many items per tile)
+#pragma unroll 1
+        for (int il = il0 + UPF * IPP; il < n_items; il += IPP) {        // only for small P (many items per row tile)
             size_t idx; float va = 0.f, vb = 0.f;
             const bool inb = unit_addr(sItem[il], s_b, s_hi0, s_wi0, s_pv, idx);
             if (inb) { va = x[idx]; vb = same_in ? va : xn[idx]; }
@@ -554,13 +564,12 @@ __global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
     const int ch0 = blockIdx.z * chunks_per_split;
     const int ch1 = min(n_chunks, ch0 + chunks_per_split);
     issue(ch0);
-    stage(0);
-    __syncthreads();
     const int ar = w_r * 64 + (lane & 31), bo = w_c * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
         const int cur = (ch - ch0) & 1;
-        const bool more = ch + 1 < ch1;
-        if (more) issue(ch + 1);
+        stage(cur);
+        __syncthreads();
+        if (ch + 1 < ch1) issue(ch + 1);
         const float* cE = sE + cur * (KPX * LDE);
         const float* cZ = sZ + cur * (KPX * LDZ);
 #pragma unroll
@@ -573,8 +582,6 @@ __global__ __launch_bounds__(WR * WC * 64, WC) void k_conv_bwd_weight(
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
         }
-        if (more) stage(cur ^ 1);
-        __syncthreads();
     }
 
     float* out = dwp + (size_t)blockIdx.z * slab_elems;
@@ -716,6 +723,8 @@ int check(const KanGeom* g, const KanBasis* b) {
     if ((g->H + 2 * g->ph - g->dh * (g->kh - 1) - 1) / g->sh + 1 != g->Ho || (g->W + 2 * g->pw - g->dw * (g->kw - 1) - 1) / g->sw + 1 != g->Wo)
         return fail("Ho/Wo inconsistent with H/W, kernel, stride, padding, dilation");
     if ((long long)g->B * g->Ho * g->Wo >= (1ll << 31) || (long long)g->B * g->H * g->W >= (1ll << 31)) return fail("pixel count exceeds int32");
+    if ((long long)g->B * g->x_bstride * 4 >= (1ll << 31) || (long long)g->B * g->y_bstride * 4 >= (1ll << 31))
+        return fail("activation tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     if (b->kind < 0 || b->kind > 2) return fail("unknown basis kind");
     if (b->act < KAN_ACT_NONE || b->act > KAN_ACT_GELU_TANH) return fail("unknown activation");
     int P = b->n_basis + (b->act != KAN_ACT_NONE);
@@ -782,19 +791,19 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_o = pl.Opad / c.TO;
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
     c.chunks = pl.Kpad / pl.KC;
-    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8);
+    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 16);
     return c;
 }
-struct BdCfg { int CT, tiles_c, tiles_p, n_ob, Opad32, chunks, splits; };
+struct BdCfg { int CH, tiles_c, tiles_p, n_ob, Opad32, chunks, splits; };   // Opad32: rows per tap of wd (multiple of 32)
 BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     BdCfg c;
-    c.CT = 128 / pl.P;
-    c.tiles_c = ceil_div(g->C, c.CT);
+    c.CH = 64 / pl.P;
+    c.tiles_c = ceil_div(g->C, 2 * c.CH);
     c.tiles_p = ceil_div((long long)g->B * g->H * g->W, 128);
-    c.n_ob = ceil_div(g->O, 32);
-    c.Opad32 = c.n_ob * 32;
+    c.n_ob = ceil_div(g->O, 16);
+    c.Opad32 = round_up(g->O, 32);
     c.chunks = g->kh * g->kw * c.n_ob;
-    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 8);
+    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 16);
     return c;
 }
 struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits; };
@@ -804,8 +813,8 @@ BwCfg bw_cfg(const KanGeom* g, const KanPlan& pl) {
     c.TR = c.TO == 128 ? 128 : 256;
     c.tiles_r = ceil_div(pl.K, c.TR);
     c.tiles_o = pl.Opad / c.TO;
-    c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 32);
-    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 16);
+    c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 16);
+    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 32);
     return c;
 }
 
@@ -814,13 +823,13 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     const int T = g->kh * g->kw;
     pl->P = b->n_basis + (b->act != KAN_ACT_NONE);
     pl->K = g->C * T * pl->P;
-    {   // LDS step of the forward kernel: KC in {32, 36} rows, IPC whole items; take the one wasting fewer rows
-        int i36 = 36 / pl->P, i32 = 32 / pl->P;
-        if (i36 > 8) i36 = 8;
-        if (i32 > 8) i32 = 8;
-        const bool use36 = (long long)i36 * pl->P * 32 > (long long)i32 * pl->P * 36;   // i36*P/36 > i32*P/32
-        pl->KC = use36 ? 36 : 32;
-        pl->IPC = use36 ? i36 : i32;
+    {   // LDS step of the forward kernel: KC in {16, 18} rows holding IPC <= 4 whole items; take the one wasting fewer rows
+        int i18 = 18 / pl->P, i16 = 16 / pl->P;
+        if (i18 > 4) i18 = 4;
+        if (i16 > 4) i16 = 4;
+        const bool use18 = (long long)i18 * pl->P * 16 > (long long)i16 * pl->P * 18;   // i18*P/18 > i16*P/16
+        pl->KC = use18 ? 18 : 16;
+        pl->IPC = use18 ? i18 : i16;
     }
     pl->Kpad = ceil_div(g->C * T, pl->IPC) * pl->KC;
     pl->Opad = round_up(g->O, 64);
@@ -864,7 +873,7 @@ int group_lanes(int HW) { int g = 4; while (g < 64 && g < HW) g <<= 1; return g;
 // ============================================================================ C ABI
 extern "C" {
 
-const char* kan_version(void) { return "kanconv 0.2 (gfx950, fp32 MFMA 32x32x2, pipelined)"; }
+const char* kan_version(void) { return "kanconv 0.3 (gfx950, fp32 MFMA 32x32x2, 4 WG/CU pipeline)"; }
 const char* kan_last_error(void) { return g_err; }
 
 int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {
@@ -896,7 +905,7 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
     if (wd) {
         BdCfg c = bd_cfg(g, pl);
         dim3 gd(c.tiles_c * 4, c.Opad32 / 32, T);
-        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CT, c.tiles_c, c.Opad32);
+        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CH, c.tiles_c, c.Opad32);
     }
     return launch_ok("pack");
 }
@@ -929,13 +938,13 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     dim3 grid(c.tiles_p, c.tiles_o, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
 #define KAN_FWD(KIND, WO, WP, KCV) \
-    hipLaunchKernelGGL((k_conv_fwd<KIND, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems)
+    hipLaunchKernelGGL((k_conv_fwd<KIND, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4))
 #define KAN_FWD_KIND(KIND)                                                     \
     do {                                                                       \
-        if (c.TO == 128 && pl.KC == 36) KAN_FWD(KIND, 2, 2, 36);               \
-        else if (c.TO == 128) KAN_FWD(KIND, 2, 2, 32);                         \
-        else if (pl.KC == 36) KAN_FWD(KIND, 1, 2, 36);                         \
-        else KAN_FWD(KIND, 1, 2, 32);                                          \
+        if (c.TO == 128 && pl.KC == 18) KAN_FWD(KIND, 2, 2, 18);               \
+        else if (c.TO == 128) KAN_FWD(KIND, 2, 2, 16);                         \
+        else if (pl.KC == 18) KAN_FWD(KIND, 1, 2, 18);                         \
+        else KAN_FWD(KIND, 1, 2, 16);                                          \
     } while (0)
     if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
@@ -958,7 +967,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     dim3 grid(c.tiles_p, c.tiles_c, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
 #define KAN_BD(KIND) \
-    hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CT, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems)
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4))
     if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else KAN_BD(KAN_BASIS_CHEBY);
@@ -977,7 +986,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     dim3 grid(c.tiles_r, c.tiles_o, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
 #define KAN_BW(KIND, WR, WC) \
-    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems)
+    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4))
 #define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
     if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);

@@ -1,0 +1,140 @@
+"""CPU: host-side logic -- the C-ABI library loads and exports every symbol the header declares, plan arithmetic,
+constructor / state_dict / factory parity with the reference surface, and loud failure without a GPU."""
+import ctypes
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import convkan_amd as K
+from convkan_amd import _lib as L
+from convkan_amd import ops
+from conftest import ROOT, golden_cases, load_golden
+from helpers import build_layer
+
+
+def test_library_exports_every_declared_symbol():
+    K.build_library()
+    lib = L.load()
+    header = open(os.path.join(ROOT, "include", "kanconv.h")).read()
+    declared = set(re.findall(r"\b(kan_[a-z_]+)\s*\(", header))
+    assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
+    raw = ctypes.CDLL(L.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert b"kanconv" in lib.kan_version()
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(L.KanGeom) == 15 * 4 + 4 + 16          # 15 ints, pad, 2 x int64
+    assert ctypes.sizeof(L.KanBasis) == 4 * 4 + 2 * 4 + 32 * 4
+    assert ctypes.sizeof(L.KanPlan) == 9 * 4 + 4 + 5 * 8
+
+
+def _plan(C, O, H, k=3, p=1, s=1, B=4, kind=L.BASIS_BSPLINE, nb=8, order=3, act=L.ACT_SILU, table=None):
+    if table is None:
+        table = tuple(float(v) for v in torch.linspace(-2.2, 2.2, 12).tolist()) if kind == L.BASIS_BSPLINE else ()
+    spec = ops.ConvSpec(kind=kind, n_basis=nb, order=order, act=act, p0=4 / 7, p1=0.0, table=table, kernel=(k, k), stride=(s, s),
+                        padding=(p, p), dilation=(1, 1))
+    return ops._plan_cached(spec, B, C, H, H, O, C, O)
+
+
+def test_plan_arithmetic():
+    g, b, p = _plan(64, 128, 16, B=256)
+    assert (p.P, p.K, p.IPC, p.KC) == (9, 64 * 9 * 9, 2, 18)
+    assert p.Kpad == (64 * 9 // 2) * 18 and p.Opad == 128
+    assert p.packed_weight_bytes == p.Kpad * p.Opad * 4
+    assert p.fwd_slab_elems == 256 * 128 * 16 * 16 and p.bwd_weight_slab_elems == p.K * p.Opad
+    assert p.fwd_splits >= 1 and p.bwd_data_splits >= 1 and p.bwd_weight_splits >= 1
+    g, b, p = _plan(3, 16, 32)                      # config 1 shape: O padded to 64
+    assert p.Opad == 64 and p.P == 9
+    g, b, p = _plan(3, 64, 224, k=11, p=2, s=4, kind=L.BASIS_CHEBY, nb=5, act=L.ACT_NONE)
+    assert (g.Ho, g.Wo) == (55, 55) and p.P == 5 and p.KC == 16 and p.IPC == 3
+
+
+def test_plan_rejects_bad_inputs():
+    with pytest.raises(L.KanConvError, match="uniform"):
+        _plan(3, 4, 8, table=(-2.2, -1.8, -1.4, -1.0, -0.6, -0.2, 0.2, 0.6, 1.0, 1.4, 1.9, 2.2))
+    with pytest.raises(L.KanConvError, match="KAN_MAX_PLANES"):
+        _plan(3, 4, 8, nb=16, order=3, table=tuple(np.linspace(-3, 3, 20).tolist()))
+    with pytest.raises(L.KanConvError):
+        _plan(3, 4, 2, k=5, p=0)                    # empty output
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_state_dict_roundtrip_with_reference_keys(name):
+    d = load_golden(name)
+    layer = build_layer(d["cfg"])
+    sd = {k[3:]: torch.from_numpy(v) for k, v in d.items() if k.startswith("sd.")}
+    assert list(layer.state_dict().keys()) == list(sd.keys())            # same keys, same order
+    layer.load_state_dict(sd, strict=True)
+    for k, v in layer.state_dict().items():
+        assert v.shape == sd[k].shape and torch.equal(v, sd[k])
+    assert "grid" not in layer.state_dict()                              # kan_layers.py: plain attribute, not a buffer
+
+
+def test_constructor_surface():
+    l = K.KANConv2DLayer(6, 8, 3, groups=2, padding=1)
+    for a in ("input_dim", "output_dim", "spline_order", "kernel_size", "padding", "stride", "dilation", "groups", "ndim", "grid_size",
+              "grid_range", "base_activation", "norm_kwargs", "dropout", "input_dim_group", "output_dim_group", "base_conv",
+              "spline_conv", "layer_norm", "prelus", "grid"):
+        assert hasattr(l, a), a
+    assert isinstance(l.base_activation, nn.GELU) and l.grid.shape == (12,) and l.input_dim_group == 3
+    assert [n for n, _ in l.named_parameters()] == ["base_conv.0.weight", "base_conv.1.weight", "spline_conv.0.weight",
+                                                    "spline_conv.1.weight", "prelus.0.weight", "prelus.1.weight"]
+    assert l.spline_conv[0].weight.shape == (4, 3 * 8, 3, 3)
+    assert isinstance(K.KANConv2DLayer(3, 4, 3, base_activation=None).base_activation, nn.Identity)
+    assert K.KANConv2DLayer(3, 4, 3, norm_layer=nn.BatchNorm2d, affine=True, bogus=1).layer_norm[0].affine       # kwargs filtered
+    f = K.FastKANConv2DLayer(3, 4, 3)
+    assert list(f.state_dict()) == ["base_conv.0.weight", "spline_conv.0.weight", "rbf.grid"] and not f.rbf.grid.requires_grad
+    c = K.ChebyKANConv2DLayer(3, 4, 3, degree=4)
+    assert list(c.state_dict()) == ["arange", "poly_conv.0.weight"] and c.arange.shape == (1, 1, 5, 1, 1)
+    for cls in (K.KANConv2DLayer, K.FastKANConv2DLayer, K.ChebyKANConv2DLayer):
+        for bad, msg in ((dict(groups=0), "positive"), (dict(groups=2), "input_dim must be divisible")):
+            with pytest.raises(ValueError, match=msg):
+                cls(3, 4, 3, **bad)
+        with pytest.raises(ValueError, match="output_dim must be divisible"):
+            cls(4, 3, 3, groups=2)
+
+
+def test_factory_signatures_and_same_padding():
+    F = K.CONV_KAN_FACTORY
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "conv"}
+    sig = inspect.signature(F["KAN"])
+    assert list(sig.parameters)[:3] == ["in_planes", "out_planes", "kernel_size"]
+    assert sig.parameters["grid_size"].default == 5 and sig.parameters["base_activation"].default is nn.GELU
+    assert inspect.signature(F["FastKAN"]).parameters["grid_range"].default == [-2, 2]
+    assert inspect.signature(F["ChebyKAN"]).parameters["degree"].default == 3
+    assert F["KAN"](3, 8, 3).padding == 1 and F["KAN"](3, 8, 5, dilation=2).padding == 4
+    assert F["KAN"](3, 8, (3, 5)).padding == (1, 2)
+    assert F["FastKAN"](3, 8, 3, l1_decay=0.0).padding == 1 and F["ChebyKAN"](3, 8, 3, degree=4, affine=True).layer_norm[0].affine
+    with pytest.raises(NotImplementedError):
+        F["KAN"](3, 8, 3, l1_decay=0.1)
+    with pytest.raises(NotImplementedError, match="HIP functor"):
+        K.KANConv2DLayer(3, 4, 3, base_activation=nn.Softplus)
+
+
+def test_no_cpu_fallback():
+    layer = K.KANConv2DLayer(3, 4, 3, padding=1)
+    with pytest.raises(L.KanConvError, match="no CPU fallback"):
+        layer(torch.randn(1, 3, 8, 8))
+
+
+def test_models_build_with_reference_parameter_names():
+    import json
+    from convkan_amd.models import alexnet_kan, cfgs, vggkan
+    assert cfgs["VGG11"] == [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512]
+    small = vggkan(3, 10, arch="VGG16_kansmall", kan_conv="KAN", classifier_type="Linear")
+    assert small.name == "VGGKAN_Linear_KAN_VGG16_kansmall"
+    with pytest.raises(ValueError, match="Unknown arch"):
+        vggkan(3, 10, arch="VGG13")
+    d = np.load(os.path.join(ROOT, "tests", "golden", "model_kan_vgg11.npz"))
+    names = json.loads(bytes(d["names"]).decode())
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear")
+    assert [n for n, _ in m.named_parameters()] == names and sum(p.numel() for p in m.parameters()) == 82964690
+    a = alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4, arch="small")
+    assert a.features[0].kernel_size == 5 and a.features[0].layer_norm[0].affine

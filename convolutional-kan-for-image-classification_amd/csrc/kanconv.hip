@@ -87,8 +87,16 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, f
         int j = j0 + ty + 8 * i, o = o0 + tx;
         float s = 0.f;
         if (j < J && o < q.O) {
-            size_t a = (size_t)pack_row(q, src_kind, j) * q.Opad + o;
-            for (int sl = 0; sl < n_slabs; ++sl) s += dwp[a + (size_t)sl * slab_elems];
+            const float* a = dwp + (size_t)pack_row(q, src_kind, j) * q.Opad + o;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f;
+            int sl = 0;
+            for (; sl + 8 <= n_slabs; sl += 8) {               // 8 loads in flight; fixed summation order => deterministic
+                const float* b = a + (size_t)sl * slab_elems;
+                s0 += b[0]; s1 += b[slab_elems]; s2 += b[2 * slab_elems]; s3 += b[3 * slab_elems];
+                s4 += b[4 * slab_elems]; s5 += b[5 * slab_elems]; s6 += b[6 * slab_elems]; s7 += b[7 * slab_elems];
+            }
+            for (; sl < n_slabs; ++sl) s0 += a[(size_t)sl * slab_elems];
+            s = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
         }
         tile[ty + 8 * i][tx] = s;
     }
@@ -134,41 +142,42 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
 }
 
 // ============================================================================ staging helpers
-// Write the P planes of one (pixel, item) unit into an LDS column.  `col` points at row 0 of the unit, `ld` is the
-// row stride, rows outside [row_lo, row_hi) (relative to `col`) are skipped.  B-spline planes are sparse (<= S+1 of
-// n_basis non-zero): zero the column, then overwrite the live rows (same lane, in-order LDS => correct).
+// Write the P planes of one (pixel, item) unit into an LDS column, branch-free.  `col` points at row 0 of the unit,
+// `ld` is the row stride; the caller guarantees that rows [0, P) of the column may be written (the weight-gradient
+// tile keeps a P-row margin on both sides for units that straddle the tile edge) and provides `dump`, an LDS word
+// nobody reads.  B-spline planes are sparse (<= S+1 of n_basis non-zero): zero the column, then overwrite the live
+// rows (same lane, in-order LDS => correct); rows of bases outside [0, n_basis) go to `dump` instead of a branch.
 template <int KIND>
 __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab, bool inb, float xa, float xb,
-                                           float* col, int ld, int row_lo, int row_hi) {
+                                           float* col, int ld, float* dump) {
     const int P = bs.P, hb = bs.hb;
     if (KIND == KAN_BASIS_BSPLINE) {
-        float base = 0.f, N[4]; int j0 = 0; bool ok = false;
+        float base = 0.f, N[4] = {0.f, 0.f, 0.f, 0.f}; int j0 = -8;
         if (inb) {
             if (hb) base = kan_act(bs.act, xa);
-            ok = bspline_uniform<false>(bs.order, xb, sTab, bs.nb + bs.order + 1, bs.inv_h, j0, N);
+            if (!bspline_uniform<false>(bs.order, xb, sTab, bs.nb + bs.order + 1, bs.inv_h, j0, N)) j0 = -8;
         }
 #pragma unroll
         for (int p = 0; p < KAN_PMAX; ++p)
-            if (p < P && p >= row_lo && p < row_hi) col[p * ld] = (p < hb) ? base : 0.f;
-        if (ok) {
+            if (p < P) col[p * ld] = (p < hb) ? base : 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int j = j0 + r, row = hb + j;
-                if (r <= bs.order && j >= 0 && j < bs.nb && row >= row_lo && row < row_hi) col[row * ld] = N[r];
+        for (int r = 0; r < 4; ++r) {
+            if (r <= bs.order) {                                     // uniform
+                const int j = j0 + r;
+                float* dst = (j >= 0 && j < bs.nb) ? col + (hb + j) * ld : dump;
+                *dst = N[r];
             }
         }
     } else {
         float v[KAN_PMAX];
-        if (inb) kan_planes<KIND, false>(bs, sTab, xa, xb, v);
-        else {
-#pragma unroll
-            for (int p = 0; p < KAN_PMAX; ++p) v[p] = 0.f;
-        }
+        kan_planes<KIND, false>(bs, sTab, xa, xb, v);
 #pragma unroll
         for (int p = 0; p < KAN_PMAX; ++p)
-            if (p < P && p >= row_lo && p < row_hi) col[p * ld] = v[p];
+            if (p < P) col[p * ld] = inb ? v[p] : 0.f;
     }
 }
+
+constexpr int KCM = 36;                        // (legacy constant kept for plan arithmetic)
 
 // Occupancy is the lever on this chip for an exact-fp32 MFMA GEMM (measured: 2 -> 4 workgroups per CU took the
 // bwd-data kernel from 79 to 120 TFLOP/s): every kernel below is sized for FOUR 256-thread workgroups per CU,
@@ -183,6 +192,11 @@ __device__ __forceinline__ kan_rsrc make_rsrc(const float* p, unsigned bytes) {
 }
 __device__ __forceinline__ float buf_load(kan_rsrc r, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 0));
+}
+// Async masked 4-byte-per-lane gather global -> LDS through the buffer descriptor: lane i lands at lds_base + 4*i
+// (lds_base WAVE-UNIFORM), an out-of-range offset lands a zero.  No VGPR destination, no ds_write.
+__device__ __forceinline__ void buf_load_lds4(kan_rsrc r, unsigned byte_off, float* lds_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_base, 4, (int)byte_off, 0, 0, 0);
 }
 // Async 16-byte-per-lane copy global -> LDS (no VGPRs): lds_base is the WAVE-UNIFORM destination, lane i lands at
 // lds_base + 16*i; the source address is per lane.
@@ -207,6 +221,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     __shared__ __attribute__((aligned(16))) float sW[2 * KC * TO];
     __shared__ float sE[2 * KC * TP];
     __shared__ float sTab[KAN_MAX_TABLE];
+    __shared__ float sDump[NT];                              // write-only sink for masked-off basis rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w_o = wave / WP, w_p = wave % WP;
@@ -264,7 +279,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;
-            if (il < IPC) stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, 0, P);
+            if (il < IPC) stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, sDump + tid);
         }
     };
 
@@ -354,8 +369,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const unsigned dz_img = (unsigned)pb * (unsigned)g.ybs;
     const int wv = __builtin_amdgcn_readfirstlane(wave);
 
-    float gr[8];
-    // issue(ch, buf): gather dz of step ch into registers; start the async copy of its weight rows into LDS buffer `buf`
+    // issue(ch, buf): start the async copies of step ch into LDS buffer `buf`: the gathered dz tile (16 outputs x 128
+    // pixels, 4 B per lane, masked by the buffer bounds check) and the weight rows (16 x 128, 16 B per lane)
     auto issue = [&](int ch, int buf) {
         const int tap = ch / n_ob, o0 = (ch - tap * n_ob) * KD;
         const int r = tap / g.kw, t = tap - r * g.kw;
@@ -363,23 +378,19 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         const int ho = hn / g.sh, wo = wn / g.sw;
         const bool ok = pv && hn >= 0 && wn >= 0 && ho * g.sh == hn && wo * g.sw == wn && ho < g.Ho && wo < g.Wo;
         const unsigned base = ok ? (dz_img + (unsigned)(ho * g.Wo + wo)) * 4u : KAN_OOB;
+        float* dW = smem + buf * (2 * KD * 128);
+        float* dG = dW + KD * 128;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-            const int o = o0 + ol0 + 2 * n;
-            gr[n] = buf_load(dz_rs, o < g.O ? base + (unsigned)o * (unsigned)HoWo * 4u : KAN_OOB);
+        for (int n = 0; n < 8; ++n) {                      // this wave's 64 pixels of row ol0 + 2n
+            const int ol = ol0 + 2 * n, o = o0 + ol;
+            buf_load_lds4(dz_rs, o < g.O ? base + (unsigned)o * (unsigned)HoWo * 4u : KAN_OOB, dG + ol * TP + (wv & 1) * 64);
         }
         const float* wsrc = wd + ((size_t)tap * Opad16 + o0) * ncol + ct * 128;
-        float* dW = smem + buf * (2 * KD * 128);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                      // 16 rows x 512 B = 8 wave-instructions of 1 KiB
             const int blk = j * 4 + wv, row = blk * 2 + (lane >> 5), c4 = lane & 31;
             glds16(wsrc + (size_t)row * ncol + c4 * 4, dW + blk * 256);
         }
-    };
-    auto stage = [&](int buf) {
-        float* dG = smem + buf * (2 * KD * 128) + KD * 128;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) dG[(ol0 + 2 * n) * TP + pxl] = gr[n];
     };
 
     f32x16 acc[2][2];
@@ -396,8 +407,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const int ar = w_r * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int ch = ch0; ch < ch1; ++ch) {
         const int cur = (ch - ch0) & 1;
-        stage(cur);
-        __syncthreads();                                   // (drains the async weight copy of this step: vmcnt(0))
+        __syncthreads();                                   // drains this step's async copies (vmcnt(0)) and orders the buffers
         if (ch + 1 < ch1) issue(ch + 1, cur ^ 1);
         const float* cW = smem + cur * (2 * KD * 128);
         const float* cG = cW + KD * 128;
@@ -465,7 +475,9 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
     DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems,
     unsigned x_bytes, unsigned dz_bytes) {
-    constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, LDE = TR + 1, LDZ = TO + 1, KPX = 16;
+    constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, KPX = 16;
+    constexpr int MRG = KAN_PMAX;                    // margin rows on both sides: units straddling the tile edge write there
+    constexpr int LDE = TR + 2 * MRG + 1, LDZ = TO + 1;
     constexpr int IPP = NT / KPX;                    // items per pass (16)
     constexpr int UPF = TR / 128;                    // units per thread with register prefetch (covers P >= 8)
     constexpr int ZL = TO * KPX / NT;                // dz loads per thread
@@ -474,6 +486,7 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     __shared__ float sZ[2 * KPX * LDZ];
     __shared__ int sItem[MAXI];                      // c | r<<16 | t<<24, or -1
     __shared__ float sTab[KAN_MAX_TABLE];
+    __shared__ float sDump[NT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int w_r = wave / WC, w_c = wave % WC;
@@ -531,14 +544,14 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
         }
     };
     auto stage = [&](int buf) {
-        float* dE = sE + buf * (KPX * LDE) + pl * LDE;
+        float* dE = sE + buf * (KPX * LDE) + pl * LDE + MRG;      // row 0 of the tile sits MRG words into the line
         float* dZ = sZ + buf * (KPX * LDZ) + pl * LDZ;
 #pragma unroll
         for (int u = 0; u < UPF; ++u) {
             const int il = il0 + u * IPP;
             if (il < n_items) {
                 const int rbase = (item_first + il) * P - k0;
-                stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, -rbase, TR - rbase);
+                stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, sDump + tid);
             }
         }
 #pragma unroll 1
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
             const bool inb = unit_addr(sItem[il], s_b, s_hi0, s_wi0, s_pv, idx);
             if (inb) { va = x[idx]; vb = same_in ? va : xn[idx]; }
             const int rbase = (item_first + il) * P - k0;
-            stage_unit<KIND>(bs, sTab, inb, va, vb, dE + rbase, 1, -rbase, TR - rbase);
+            stage_unit<KIND>(bs, sTab, inb, va, vb, dE + rbase, 1, sDump + tid);
         }
 #pragma unroll
         for (int n = 0; n < ZL; ++n) dZ[il0 + n * IPP] = zr[n];
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
         stage(cur);
         __syncthreads();
         if (ch + 1 < ch1) issue(ch + 1);
-        const float* cE = sE + cur * (KPX * LDE);
+        const float* cE = sE + cur * (KPX * LDE) + MRG;
         const float* cZ = sZ + cur * (KPX * LDZ);
 #pragma unroll
         for (int kk = 0; kk < KPX / 2; ++kk) {
@@ -663,45 +676,71 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
                                                       const float* __restrict__ prelu_a, float* __restrict__ dz,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dprelu,
                                                       int n_planes, int Cn, int HW, long long bstride) {
+    constexpr int EPL = 16;                         // elements per lane held in registers between the two passes
     __shared__ float s_da[256 / G];
     const int tid = threadIdx.x, sub = tid % G;
-    const int plane = blockIdx.x * (256 / G) + tid / G;
+    const bool has_p = prelu_a != nullptr;
+    const float a = has_p ? prelu_a[0] : 1.f;
+    const bool in_regs = HW <= G * EPL;             // uniform
+    float sa_total = 0.f;                           // PReLU-slope gradient of every plane this workgroup visits
+    // grid-stride over groups of 256/G planes: the grid is capped so that the single-address atomic on dprelu
+    // (one per workgroup) stays cheap -- 16 k workgroups hammering one word cost 190 us
+    for (int pg = blockIdx.x; pg * (256 / G) < n_planes; pg += gridDim.x) {
+    const int plane = pg * (256 / G) + tid / G;
     const bool act = plane < n_planes;
     const int b = act ? plane / Cn : 0, c = act ? plane - b * Cn : 0;
     const size_t base = (size_t)b * bstride + (size_t)c * HW;
     const float mu = act ? mean_i[plane] : 0.f, rs = act ? rstd_i[plane] : 0.f;
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
-    const bool has_p = prelu_a != nullptr;
-    const float a = has_p ? prelu_a[0] : 1.f;
+    float rn[EPL], rd[EPL];                         // normalised value, d loss / d normalised value
     float s1 = 0.f, s2 = 0.f, sa = 0.f, sg = 0.f, sb = 0.f;
-    if (act) for (int i = sub; i < HW; i += G) {
-        float nh = (z[base + i] - mu) * rs;
-        float n = nh * ga + be;
-        float g = dy[base + i];
-        bool neg = has_p && !(n > 0.f);
-        float dn = neg ? a * g : g;
+    auto visit = [&](float zv, float g, float& nh, float& dnh) {
+        nh = (zv - mu) * rs;
+        const float n = nh * ga + be;
+        const bool neg = has_p && !(n > 0.f);
+        const float dn = neg ? a * g : g;
         if (neg) sa += n * g;
         sb += dn; sg += dn * nh;
-        float dnh = dn * ga;
+        dnh = dn * ga;
         s1 += dnh; s2 += dnh * nh;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = sub + e * G;
+            rn[e] = 0.f; rd[e] = 0.f;
+            if (act && i < HW) visit(z[base + i], dy[base + i], rn[e], rd[e]);
+        }
+    } else if (act) {
+        for (int i = sub; i < HW; i += G) { float nh, dnh; visit(z[base + i], dy[base + i], nh, dnh); }
     }
     s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
     sa = group_sum<G>(sa); sg = group_sum<G>(sg); sb = group_sum<G>(sb);
     const float m1 = s1 / (float)HW, m2 = s2 / (float)HW;
-    if (act) for (int i = sub; i < HW; i += G) {
-        float nh = (z[base + i] - mu) * rs;
-        float n = nh * ga + be;
-        float g = dy[base + i];
-        bool neg = has_p && !(n > 0.f);
-        float dnh = (neg ? a * g : g) * ga;
-        dz[base + i] = rs * (dnh - m1 - nh * m2);
+    if (in_regs) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int i = sub + e * G;
+            if (act && i < HW) dz[base + i] = rs * (rd[e] - m1 - rn[e] * m2);
+        }
+    } else if (act) {
+        for (int i = sub; i < HW; i += G) {
+            float nh = (z[base + i] - mu) * rs;
+            float n = nh * ga + be;
+            float g = dy[base + i];
+            bool neg = has_p && !(n > 0.f);
+            float dnh = (neg ? a * g : g) * ga;
+            dz[base + i] = rs * (dnh - m1 - nh * m2);
+        }
     }
     if (act && sub == 0) {
         if (dgamma) atomicAdd(&dgamma[c], sg);
         if (dbeta) atomicAdd(&dbeta[c], sb);
+        sa_total += sa;
     }
+    }                                               // grid-stride loop
     if (dprelu) {                                   // one atomic per workgroup
-        if (sub == 0) s_da[tid / G] = act ? sa : 0.f;
+        if (sub == 0) s_da[tid / G] = sa_total;
         __syncthreads();
         if (tid == 0) {
             float t = 0.f;
@@ -766,14 +805,23 @@ DevBasis dev_basis(const KanBasis* b) {
     return d;
 }
 
+// Split-K factor.  The conv kernels keep 4 workgroups per CU resident (1024 on the chip), so a grid of W workgroups
+// runs in ceil(W/1024) rounds and wastes the empty part of the last one (1184 workgroups = 58 % efficiency).  Model the
+// time of s splits as rounds(s) * (steps per workgroup + a fixed per-workgroup cost of ~6 steps for prologue, tile
+// store and the extra slab) and take the cheapest s with at least min_chunks steps per split and no empty split.
 int pick_splits(long long tiles, int chunks, int min_chunks) {
-    if (tiles >= 384) return 1;
-    int want = ceil_div(768, tiles);
+    const long long SLOTS = 1024;
     int cap = chunks / min_chunks; if (cap < 1) cap = 1;
-    int s = want < cap ? want : cap;
-    if (s < 1) s = 1;
-    int cps = ceil_div(chunks, s);
-    return ceil_div(chunks, cps);                 // no empty splits
+    if (cap > 1024) cap = 1024;
+    int best = 1; long long best_cost = -1;
+    for (int s = 1; s <= cap; ++s) {
+        const int cps = ceil_div(chunks, s);
+        if (ceil_div(chunks, cps) != s) continue;            // would leave an empty split
+        const long long rounds = (tiles * s + SLOTS - 1) / SLOTS;
+        const long long cost = rounds * (cps + 6);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 int launch_ok(const char* what) {
@@ -791,7 +839,7 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_o = pl.Opad / c.TO;
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
     c.chunks = pl.Kpad / pl.KC;
-    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 16);
+    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8);
     return c;
 }
 struct BdCfg { int CH, tiles_c, tiles_p, n_ob, Opad32, chunks, splits; };   // Opad32: rows per tap of wd (multiple of 32)
@@ -803,7 +851,7 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.n_ob = ceil_div(g->O, 16);
     c.Opad32 = round_up(g->O, 32);
     c.chunks = g->kh * g->kw * c.n_ob;
-    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 16);
+    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 8);
     return c;
 }
 struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits; };
@@ -814,7 +862,7 @@ BwCfg bw_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_r = ceil_div(pl.K, c.TR);
     c.tiles_o = pl.Opad / c.TO;
     c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 16);
-    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 32);
+    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 16);
     return c;
 }
 
@@ -863,7 +911,9 @@ template <int G>
 void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW, long long bs) {
     int ppb = 256 / G;
-    hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(ceil_div(planes, ppb)), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
+    int blocks = ceil_div(planes, ppb);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
                        dbeta, dprelu, planes, Cn, HW, bs);
 }
 int group_lanes(int HW) { int g = 4; while (g < 64 && g < HW) g <<= 1; return g; }

@@ -33,6 +33,7 @@ int fail(const char* fmt, const char* a = "") {
 
 struct DevGeom {
     int B, C, H, W, O, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
+    int howo_shift, wo_shift;    // log2(Ho*Wo), log2(Wo) when both are powers of two, else -1 (pixel decode by shifts)
     long long xbs, ybs;
 };
 
@@ -147,14 +148,41 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
 // tile keeps a P-row margin on both sides for units that straddle the tile edge) and provides `dump`, an LDS word
 // nobody reads.  B-spline planes are sparse (<= S+1 of n_basis non-zero): zero the column, then overwrite the live
 // rows (same lane, in-order LDS => correct); rows of bases outside [0, n_basis) go to `dump` instead of a branch.
-template <int KIND>
+// FAST != 0 fixes the reference's default B-spline configuration at compile time (grid 5, order 3 => 8 bases, base
+// branch present => P = 9; FAST 1: SiLU, FAST 2: GELU): straight-line code, no runtime loop bounds, fewer live scalars.
+// That matters twice on gfx950: VALU instructions steal fp32-MFMA issue time, and SGPR spills are VALU (v_readlane).
+template <int KIND, int FAST>
 __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab, bool inb, float xa, float xb,
                                            float* col, int ld, float* dump) {
+    if (KIND == KAN_BASIS_BSPLINE && FAST != 0) {
+        float base = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, N3 = 0.f; int j0 = -8;
+        const bool live = inb && xa >= bs.g0 && xa < bs.gN;             // NaN fails both, as the reference's indicator
+        if (inb) base = FAST == 1 ? xa * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xa * -1.44269504088896340736f))
+                                  : kan_act(KAN_ACT_GELU, xa);
+        if (live) {
+            const int i = min((int)((xa - bs.g0) * bs.inv_h), 10);       // 11 knot intervals
+            const float u = fminf(fmaxf((xa - sTab[i]) * bs.inv_h, 0.f), 1.f), v = 1.f - u;
+            const float u2 = u * u, u3 = u2 * u, k6 = 1.f / 6.f;
+            N0 = k6 * v * v * v;
+            N1 = k6 * (3.f * u3 - 6.f * u2 + 4.f);
+            N2 = k6 * (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f);
+            N3 = k6 * u3;
+            j0 = i - 3;
+        }
+        col[0] = base;
+#pragma unroll
+        for (int p = 1; p < 9; ++p) col[p * ld] = 0.f;
+        *(((unsigned)j0 < 8u) ? col + (1 + j0) * ld : dump) = N0;
+        *(((unsigned)(j0 + 1) < 8u) ? col + (2 + j0) * ld : dump) = N1;
+        *(((unsigned)(j0 + 2) < 8u) ? col + (3 + j0) * ld : dump) = N2;
+        *(((unsigned)(j0 + 3) < 8u) ? col + (4 + j0) * ld : dump) = N3;
+        return;
+    }
     const int P = bs.P, hb = bs.hb;
     if (KIND == KAN_BASIS_BSPLINE) {
         float base = 0.f, N[4] = {0.f, 0.f, 0.f, 0.f}; int j0 = -8;
         if (inb) {
-            if (hb) base = kan_act(bs.act, xa);
+            if (hb) base = kan_act_fast(bs.act, xa);
             if (!bspline_uniform<false>(bs.order, xb, sTab, bs.nb + bs.order + 1, bs.inv_h, j0, N)) j0 = -8;
         }
 #pragma unroll
@@ -164,7 +192,7 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
         for (int r = 0; r < 4; ++r) {
             if (r <= bs.order) {                                     // uniform
                 const int j = j0 + r;
-                float* dst = (j >= 0 && j < bs.nb) ? col + (hb + j) * ld : dump;
+                float* dst = ((unsigned)j < (unsigned)bs.nb) ? col + (hb + j) * ld : dump;
                 *dst = N[r];
             }
         }
@@ -208,7 +236,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
 // ============================================================================ forward
 // Workgroup tile: TO = WO*64 outputs x TP = WP*64 output pixels, one 64x64 wave tile per wave (2x2 MFMA 32x32x2).
 // Pipeline per step: [expand + write step s into buffer b] barrier [issue global loads of step s+1] [MFMAs on b].
-template <int KIND, int WO, int WP, int KC>
+template <int KIND, int FAST, int WO, int WP, int KC>
 __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp, float* __restrict__ z,
     DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes) {
@@ -223,28 +251,30 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     __shared__ float sTab[KAN_MAX_TABLE];
     __shared__ float sDump[NT];                              // write-only sink for masked-off basis rows
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform => scalar registers
     const int w_o = wave / WP, w_p = wave % WP;
-    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = bs.P;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? 9 : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
     const int px_tile0 = blockIdx.x * TP, o_tile0 = blockIdx.y * TO;
-    const int pxl = tid % TP, il0 = tid / TP;
+    const int pxl = (wave % (TP / 64)) * 64 + lane, il0 = wave / (TP / 64);
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     for (int i = tid; i < 2 * KC * TP; i += NT) sE[i] = 0.f;            // pad rows stay zero for the whole kernel
 
     const int my_px = px_tile0 + pxl;
     const bool pv = my_px < Mtot;
-    int hi0, wi0; long long xoff;
+    int hi0, wi0, pbase;                                     // pbase: element offset of (image, hi0, wi0); may be negative
     {
         int b = my_px / HoWo, hw = my_px - b * HoWo;
         int ho = hw / g.Wo, wo = hw - ho * g.Wo;
         hi0 = ho * g.sh - g.ph; wi0 = wo * g.sw - g.pw;
-        xoff = (long long)b * g.xbs;
+        pbase = b * (int)g.xbs + hi0 * g.W + wi0;
     }
-    const bool same_in = (x == xn);
-    const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(xn, x_bytes);
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const bool same_in = (KIND != KAN_BASIS_RBF) || (x == xn);     // only FastKAN evaluates its basis on a second tensor
+    const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes);
+    const int wv = wave;
+    const unsigned wlane = (unsigned)((lane / (TO / 4)) * Opad + (lane % (TO / 4)) * 4) * 4u;   // this lane inside a 1-KiB weight block
 
     float xa[UMAX], xb[UMAX]; unsigned inb_mask = 0;
 
@@ -254,24 +284,27 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
         inb_mask = 0;
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
-            const int il = il0 + u * IPP;
-            const int item = __builtin_amdgcn_readfirstlane(ch * IPC + il);
+            const int il = il0 + u * IPP;                                          // scalar
+            const int item = ch * IPC + il;
             const int c = item / T, tap = item - c * T;
             const int r = tap / g.kw, t = tap - r * g.kw;
-            const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
+            const int dr = r * g.dh, dt = t * g.dw;
+            const int hi = hi0 + dr, wi = wi0 + dt;
             const bool inb = il < IPC && pv && item < NI && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-            const unsigned off = inb ? (unsigned)(xoff + (long long)c * HW + hi * g.W + wi) * 4u : KAN_OOB;
+            const unsigned off = inb ? (unsigned)(pbase + (c * HW + dr * g.W + dt)) * 4u : KAN_OOB;
             xa[u] = buf_load(x_rs, off);
             xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
             inb_mask |= (inb ? 1u : 0u) << u;
         }
-        const float* wsrc = wp + (size_t)ch * KC * Opad + o_tile0;
+        const char* wsrc = (const char*)(wp + (size_t)ch * KC * Opad + o_tile0);      // scalar
         float* dW = sW + buf * (KC * TO);
 #pragma unroll
         for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
             const int q = j * NW + wv;                     // 1-KiB block index inside the weight step (wave-uniform)
-            const int row = q * RPI + lane / (TO / 4), c4 = lane % (TO / 4);
-            if (q < NQ && row < KC) glds16(wsrc + (size_t)row * Opad + c4 * 4, dW + q * 256);
+            if (q < NQ) {
+                if (KC % RPI == 0 || q * RPI + (int)(lane / (TO / 4)) < KC)
+                    glds16((const float*)(wsrc + (size_t)q * RPI * Opad * 4 + wlane), dW + q * 256);
+            }
         }
     };
     auto stage = [&](int buf) {
@@ -279,7 +312,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;
-            if (il < IPC) stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, sDump + tid);
+            if (il < IPC) stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, sDump + tid);
         }
     };
 
@@ -349,13 +382,14 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * KD * 128];   // 2 x (sW 16x128 + sG 16x128) = 32 KB; epilogue 64x128
     __shared__ float sTab[KAN_MAX_TABLE];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform => scalar registers
     const int w_r = wave >> 1, w_p = wave & 1;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, P = bs.P;
     const int Min = g.B * HW;
     const int px_tile0 = blockIdx.x * TP, ct = blockIdx.y;
     const int ncol = n_ct * 128;
-    const int pxl = tid & 127, ol0 = tid >> 7;
+    const int pxl = (wave & 1) * 64 + lane, ol0 = wave >> 1;
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     const int my_px = px_tile0 + pxl;
@@ -367,29 +401,52 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     }
     const kan_rsrc dz_rs = make_rsrc(dz, dz_bytes);
     const unsigned dz_img = (unsigned)pb * (unsigned)g.ybs;
-    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int wv = wave;
+
+    // On gfx950 the fp32 MFMA shares the vector ALU: every VALU instruction in this loop costs ~4.5 cycles of matrix
+    // time (tools/probe/mfma_probe.hip), so everything that only depends on the tap is cached across the n_ob steps
+    // of a tap, per-lane offsets are precomputed, and the per-step parts ride in scalar registers.
+    int cur_tap = -1; unsigned base = KAN_OOB;                // gather offset of this thread's pixel for cur_tap
+    const unsigned wlane = (unsigned)((lane >> 5) * ncol + (lane & 31) * 4) * 4u;      // byte offset of this lane in a 2-row weight block
+    const unsigned row_bytes = (unsigned)HoWo * 4u;
+    const bool o_full = (n_ob * KD == g.O);                   // no ragged last output block
 
     // issue(ch, buf): start the async copies of step ch into LDS buffer `buf`: the gathered dz tile (16 outputs x 128
     // pixels, 4 B per lane, masked by the buffer bounds check) and the weight rows (16 x 128, 16 B per lane)
     auto issue = [&](int ch, int buf) {
-        const int tap = ch / n_ob, o0 = (ch - tap * n_ob) * KD;
-        const int r = tap / g.kw, t = tap - r * g.kw;
-        const int hn = ph_ + g.ph - r * g.dh, wn = pw_ + g.pw - t * g.dw;
-        const int ho = hn / g.sh, wo = wn / g.sw;
-        const bool ok = pv && hn >= 0 && wn >= 0 && ho * g.sh == hn && wo * g.sw == wn && ho < g.Ho && wo < g.Wo;
-        const unsigned base = ok ? (dz_img + (unsigned)(ho * g.Wo + wo)) * 4u : KAN_OOB;
-        float* dW = smem + buf * (2 * KD * 128);
-        float* dG = dW + KD * 128;
-#pragma unroll
-        for (int n = 0; n < 8; ++n) {                      // this wave's 64 pixels of row ol0 + 2n
-            const int ol = ol0 + 2 * n, o = o0 + ol;
-            buf_load_lds4(dz_rs, o < g.O ? base + (unsigned)o * (unsigned)HoWo * 4u : KAN_OOB, dG + ol * TP + (wv & 1) * 64);
+        const int tap = ch / n_ob, o0 = (ch - tap * n_ob) * KD;                       // scalar
+        if (tap != cur_tap) {                                                          // uniform: once per n_ob steps
+            cur_tap = tap;
+            const int r = tap / g.kw, t = tap - r * g.kw;
+            const int hn = ph_ + g.ph - r * g.dh, wn = pw_ + g.pw - t * g.dw;
+            int ho = hn, wo = wn; bool ok = pv && hn >= 0 && wn >= 0;
+            if (g.sh != 1 || g.sw != 1) {                                              // uniform; strided convs only
+                ho = hn / g.sh; wo = wn / g.sw;
+                ok = ok && ho * g.sh == hn && wo * g.sw == wn;
+            }
+            ok = ok && ho < g.Ho && wo < g.Wo;
+            base = ok ? (dz_img + (unsigned)(ho * g.Wo + wo)) * 4u : KAN_OOB;
         }
-        const float* wsrc = wd + ((size_t)tap * Opad16 + o0) * ncol + ct * 128;
+        float* dW = smem + buf * (2 * KD * 128);
+        float* dG = dW + KD * 128 + (wv & 1) * 64;
+        const unsigned so0 = (unsigned)(o0 + ol0) * row_bytes;                         // scalar part of the offset
+        if (o_full) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n)                    // this wave's 64 pixels of row ol0 + 2n
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dG + (ol0 + 2 * n) * TP), 4,
+                                                         (int)base, (int)(so0 + (unsigned)(2 * n) * row_bytes), 0, 0);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const int ol = ol0 + 2 * n;
+                buf_load_lds4(dz_rs, o0 + ol < g.O ? base + (unsigned)(o0 + ol) * row_bytes : KAN_OOB, dG + ol * TP);
+            }
+        }
+        const char* wsrc = (const char*)(wd + ((size_t)tap * Opad16 + o0) * ncol + ct * 128);      // scalar
 #pragma unroll
         for (int j = 0; j < 2; ++j) {                      // 16 rows x 512 B = 8 wave-instructions of 1 KiB
-            const int blk = j * 4 + wv, row = blk * 2 + (lane >> 5), c4 = lane & 31;
-            glds16(wsrc + (size_t)row * ncol + c4 * 4, dW + blk * 256);
+            const int blk = j * 4 + wv;
+            glds16((const float*)(wsrc + (size_t)blk * 2 * ncol * 4 + wlane), dW + blk * 256);
         }
     };
 
@@ -444,7 +501,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
                     }
         }
         __syncthreads();
-        for (int cl = tid >> 7; cl < CH; cl += 2) {
+        for (int cl = ol0; cl < CH; cl += 2) {
             const int c = (ct * 2 + half) * CH + cl;
             if (c >= g.C || !pv) continue;
             const size_t idx = (size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_);
@@ -470,7 +527,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
 // Tile: TR = WR*64 rows of the FLAT packed K axis (row = item*P + p) x TO = WC*64 outputs; depth steps of 16 output
 // pixels.  The expanded operand is written [pixel][row] (pad 1) so that both the per-pixel writes and the per-row
 // MFMA reads are bank-conflict free (2-way at worst on the writes, which ds_write_b32 absorbs).
-template <int KIND, int WR, int WC>
+template <int KIND, int FAST, int WR, int WC>
 __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
     DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems,
@@ -488,9 +545,10 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     __shared__ float sTab[KAN_MAX_TABLE];
     __shared__ float sDump[NT];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform => scalar registers
     const int w_r = wave / WC, w_c = wave % WC;
-    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = bs.P;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? 9 : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
     const int k0 = blockIdx.x * TR, o_tile0 = blockIdx.y * TO;
     const int item_first = k0 / P;
@@ -506,41 +564,55 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
         }
         sItem[i] = v;
     }
-    const bool same_in = (x == xn);
+    const bool same_in = (KIND != KAN_BASIS_RBF) || (x == xn);
     __syncthreads();
 
     float xa[UPF], xb[UPF], zr[ZL]; unsigned inb_mask = 0;
     int s_b = 0, s_hi0 = 0, s_wi0 = 0; bool s_pv = false;    // pixel decode of the staged step (for units beyond UPF)
-    const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(xn, x_bytes), dz_rs = make_rsrc(dz, dz_bytes);
+    const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes), dz_rs = make_rsrc(dz, dz_bytes);
+    const bool o_full = o_tile0 + TO <= g.O;                   // no ragged output tile
+    const unsigned row_bytes = (unsigned)HoWo * 4u;
 
-    auto unit_addr = [&](int it, int b, int hi0, int wi0, bool pv, size_t& idx) -> bool {
+    auto unit_addr = [&](int it, int b, int hi0, int wi0, bool pv, unsigned& idx) -> bool {     // idx: element offset (32 bit)
         const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
         const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
-        idx = (size_t)b * g.xbs + (size_t)c * HW + (size_t)(hi * g.W + wi);
+        idx = (unsigned)(b * (int)g.xbs + c * HW + hi * g.W + wi);
         return pv && it >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
     };
     auto issue = [&](int ch) {
         const int px = ch * KPX + pl;
         const bool pv = px < Mtot;
-        const int b = px / HoWo, hw = px - b * HoWo;
-        const int ho = hw / g.Wo, wo = hw - ho * g.Wo;
+        int b, hw, ho, wo;
+        if (g.howo_shift >= 0) {                               // uniform: power-of-two planes decode by shifts
+            b = px >> g.howo_shift; hw = px & (HoWo - 1);
+            ho = hw >> g.wo_shift; wo = hw & (g.Wo - 1);
+        } else {
+            b = px / HoWo; hw = px - b * HoWo;
+            ho = hw / g.Wo; wo = hw - ho * g.Wo;
+        }
         s_b = b; s_hi0 = ho * g.sh - g.ph; s_wi0 = wo * g.sw - g.pw; s_pv = pv;
         inb_mask = 0;
 #pragma unroll
         for (int u = 0; u < UPF; ++u) {
             const int il = il0 + u * IPP;
-            size_t idx;
+            unsigned idx;
             const bool inb = il < n_items && unit_addr(sItem[min(il, MAXI - 1)], b, s_hi0, s_wi0, pv, idx);
-            const unsigned off = inb ? (unsigned)idx * 4u : KAN_OOB;
+            const unsigned off = inb ? idx * 4u : KAN_OOB;
             xa[u] = buf_load(x_rs, off);
             xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
             inb_mask |= (inb ? 1u : 0u) << u;
         }
-        const unsigned zbase = pv ? ((unsigned)b * (unsigned)g.ybs + (unsigned)hw) * 4u : KAN_OOB;
+        const unsigned zbase = pv ? ((unsigned)b * (unsigned)g.ybs + (unsigned)hw + (unsigned)(o_tile0 + il0) * (unsigned)HoWo) * 4u : KAN_OOB;
+        if (o_full) {                                          // uniform: the per-output part of the offset rides in a scalar
 #pragma unroll
-        for (int n = 0; n < ZL; ++n) {
-            const int o = o_tile0 + il0 + n * IPP;
-            zr[n] = buf_load(dz_rs, o < g.O ? zbase + (unsigned)o * (unsigned)HoWo * 4u : KAN_OOB);
+            for (int n = 0; n < ZL; ++n)
+                zr[n] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(dz_rs, (int)zbase, (int)((unsigned)(n * IPP) * row_bytes), 0));
+        } else {
+#pragma unroll
+            for (int n = 0; n < ZL; ++n) {
+                const int o = o_tile0 + il0 + n * IPP;
+                zr[n] = buf_load(dz_rs, o < g.O ? zbase + (unsigned)(n * IPP) * row_bytes : KAN_OOB);
+            }
         }
     };
     auto stage = [&](int buf) {
@@ -551,16 +623,16 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
             const int il = il0 + u * IPP;
             if (il < n_items) {
                 const int rbase = (item_first + il) * P - k0;
-                stage_unit<KIND>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, sDump + tid);
+                stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, sDump + tid);
             }
         }
 #pragma unroll 1
         for (int il = il0 + UPF * IPP; il < n_items; il += IPP) {        // only for small P (many items per row tile)
-            size_t idx; float va = 0.f, vb = 0.f;
+            unsigned idx; float va = 0.f, vb = 0.f;
             const bool inb = unit_addr(sItem[il], s_b, s_hi0, s_wi0, s_pv, idx);
             if (inb) { va = x[idx]; vb = same_in ? va : xn[idx]; }
             const int rbase = (item_first + il) * P - k0;
-            stage_unit<KIND>(bs, sTab, inb, va, vb, dE + rbase, 1, sDump + tid);
+            stage_unit<KIND, FAST>(bs, sTab, inb, va, vb, dE + rbase, 1, sDump + tid);
         }
 #pragma unroll
         for (int n = 0; n < ZL; ++n) dZ[il0 + n * IPP] = zr[n];
@@ -786,8 +858,12 @@ int check(const KanGeom* g, const KanBasis* b) {
     return 0;
 }
 
+int log2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
+
 DevGeom dev_geom(const KanGeom* g) {
-    DevGeom d{g->B, g->C, g->H, g->W, g->O, g->Ho, g->Wo, g->kh, g->kw, g->sh, g->sw, g->ph, g->pw, g->dh, g->dw, g->x_bstride, g->y_bstride};
+    DevGeom d{g->B, g->C, g->H, g->W, g->O, g->Ho, g->Wo, g->kh, g->kw, g->sh, g->sw, g->ph, g->pw, g->dh, g->dw, -1, -1, g->x_bstride, g->y_bstride};
+    const int a = log2_exact(g->Ho * g->Wo), b = log2_exact(g->Wo);
+    if (a >= 0 && b >= 0) { d.howo_shift = a; d.wo_shift = b; }
     return d;
 }
 
@@ -795,12 +871,13 @@ DevBasis dev_basis(const KanBasis* b) {
     DevBasis d;
     d.kind = b->kind; d.nb = b->n_basis; d.order = b->order; d.act = b->act;
     d.hb = b->act != KAN_ACT_NONE ? 1 : 0; d.P = b->n_basis + d.hb;
-    d.p0 = b->p0; d.p1 = b->p1; d.inv_h = 0.f;
+    d.p0 = b->p0; d.p1 = b->p1; d.inv_h = 0.f; d.g0 = 0.f; d.gN = 0.f;
     for (int i = 0; i < KAN_MAX_TABLE; ++i) d.tab[i] = b->table[i];
     if (b->kind == KAN_BASIS_BSPLINE) {
         int nk = b->n_basis + b->order + 1;
         float span = b->table[nk - 1] - b->table[0];
         d.inv_h = span > 0.f ? (float)(nk - 1) / span : 0.f;
+        d.g0 = b->table[0]; d.gN = b->table[nk - 1];
     }
     return d;
 }
@@ -890,6 +967,14 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_splits = fwd_cfg(g, *pl).splits;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = bw_cfg(g, *pl).splits;
+    return 0;
+}
+
+// Compile-time specialisation available?  1: B-spline grid 5 / order 3 with SiLU base, 2: same with GELU, 0: generic.
+int fast_variant(const KanBasis* b) {
+    if (b->kind != KAN_BASIS_BSPLINE || b->n_basis != 8 || b->order != 3) return 0;
+    if (b->act == KAN_ACT_SILU) return 1;
+    if (b->act == KAN_ACT_GELU) return 2;
     return 0;
 }
 
@@ -987,8 +1072,9 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_p, c.tiles_o, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
-#define KAN_FWD(KIND, WO, WP, KCV) \
-    hipLaunchKernelGGL((k_conv_fwd<KIND, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4))
+#define KAN_FWD(KIND, WO, WP, KCV) KAN_FWD2(KIND, 0, WO, WP, KCV)
+#define KAN_FWD2(KIND, FAST, WO, WP, KCV) \
+    hipLaunchKernelGGL((k_conv_fwd<KIND, FAST, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4))
 #define KAN_FWD_KIND(KIND)                                                     \
     do {                                                                       \
         if (c.TO == 128 && pl.KC == 18) KAN_FWD(KIND, 2, 2, 18);               \
@@ -996,10 +1082,14 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         else if (pl.KC == 18) KAN_FWD(KIND, 1, 2, 18);                         \
         else KAN_FWD(KIND, 1, 2, 16);                                          \
     } while (0)
-    if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
+    const int fast = fast_variant(b);
+    if (fast && c.TO == 128) { if (fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 2, 2, 18); else KAN_FWD2(KAN_BASIS_BSPLINE, 2, 2, 2, 18); }
+    else if (fast) { if (fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 1, 2, 18); else KAN_FWD2(KAN_BASIS_BSPLINE, 2, 1, 2, 18); }
+    else if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
     else KAN_FWD_KIND(KAN_BASIS_CHEBY);
 #undef KAN_FWD_KIND
+#undef KAN_FWD2
 #undef KAN_FWD
     return launch_ok("conv_fwd");
 }
@@ -1035,13 +1125,18 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_r, c.tiles_o, c.splits);
     int cps = ceil_div(c.chunks, c.splits);
-#define KAN_BW(KIND, WR, WC) \
-    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4))
+#define KAN_BW(KIND, WR, WC) KAN_BW2(KIND, 0, WR, WC)
+#define KAN_BW2(KIND, FAST, WR, WC) \
+    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4))
 #define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
-    if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
+    const int fast = fast_variant(b);
+    if (fast && c.TO == 128) { if (fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 2, 2); else KAN_BW2(KAN_BASIS_BSPLINE, 2, 2, 2); }
+    else if (fast) { if (fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 4, 1); else KAN_BW2(KAN_BASIS_BSPLINE, 2, 4, 1); }
+    else if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
     else KAN_BW_KIND(KAN_BASIS_CHEBY);
 #undef KAN_BW_KIND
+#undef KAN_BW2
 #undef KAN_BW
     return launch_ok("conv_bwd_weight");
 }

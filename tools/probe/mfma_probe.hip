@@ -9,8 +9,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <int V>
-__global__ __launch_bounds__(256) void probe(const float* __restrict__ src, float* __restrict__ out, int iters) {
+template <int V, int NV>
+__global__ __launch_bounds__(256, 4) void probe(const float* __restrict__ src, float* __restrict__ out, int iters) {
     __shared__ float sA[2 * 16 * 128], sB[2 * 16 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * 16 * 128; i += 256) { sA[i] = src[i]; sB[i] = src[i + 4096]; }
@@ -20,6 +20,7 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
     const int ao = (wave >> 1) * 64 + (lane & 31), bp = (wave & 1) * 64 + (lane & 31), kh2 = lane >> 5;
     float a0 = src[tid], a1 = src[tid + 256], b0 = src[tid + 512], b1 = src[tid + 768];
     float g[10];
+    float vv = src[tid + 1024]; int si = iters;
     for (int it = 0; it < iters; ++it) {
         const int cur = it & 1;
         if (V >= 3) {
@@ -37,6 +38,14 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
             acc[0][1] = MFMA32(a0, b1, acc[0][1]);
             acc[1][0] = MFMA32(a1, b0, acc[1][0]);
             acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+            if (V >= 4) {                                   // NV dependent VALU ops per 4 MFMAs (address-math stand-in)
+#pragma unroll
+                for (int q = 0; q < NV; ++q) vv = vv * 1.0001f + 0.5f;
+            }
+            if (V >= 5) {                                   // NV scalar ops per 4 MFMAs
+#pragma unroll
+                for (int q = 0; q < NV; ++q) si = __builtin_amdgcn_readfirstlane(si * 3 + 1);
+            }
         }
         if (V >= 3) {
 #pragma unroll
@@ -45,22 +54,22 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ src, floa
         }
         if (V >= 2) __syncthreads();
     }
-    float s = 0.f;
+    float s = vv + (float)si;
     for (int a = 0; a < 2; ++a) for (int b = 0; b < 2; ++b) for (int r = 0; r < 16; ++r) s += acc[a][b][r];
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int V>
+template <int V, int NV = 0>
 void run(const float* src, float* out, int blocks, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+    (void)hipGetLastError(); hipLaunchKernelGGL((probe<V, NV>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(probe<V>, dim3(blocks), dim3(256), 0, 0, src, out, iters);
+    (void)hipGetLastError(); hipLaunchKernelGGL((probe<V, NV>), dim3(blocks), dim3(256), 0, 0, src, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double flops = (double)blocks * 4 * iters * 32 * 4096.0;
-    printf("variant %d blocks %5d (%.1f per CU): %.3f ms  %.1f TFLOP/s\n", V, blocks, blocks / 256.0, ms, flops / ms / 1e9);
+    printf("variant %d NV %2d blocks %5d (%.1f per CU): %.3f ms  %.1f TFLOP/s\n", V, NV, blocks, blocks / 256.0, ms, flops / ms / 1e9);
 }
 
 int main() {
@@ -71,11 +80,17 @@ int main() {
     float* h = (float*)malloc(64 * 4096 * 4);
     for (int i = 0; i < 64 * 4096; ++i) h[i] = (float)((i * 2654435761u >> 8) & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(src, h, 64 * 4096 * 4, hipMemcpyHostToDevice);
-    for (int blocks : {256, 512, 1024, 2048, 4096}) {
+    for (int blocks : {1024, 4096}) {
         run<0>(src, out, blocks, 2000);
-        run<1>(src, out, blocks, 2000);
         run<2>(src, out, blocks, 2000);
         run<3>(src, out, blocks, 2000);
+        run<4, 8>(src, out, blocks, 2000);
+        run<4, 16>(src, out, blocks, 2000);
+        run<4, 32>(src, out, blocks, 2000);
+        run<4, 64>(src, out, blocks, 2000);
+        run<5, 8>(src, out, blocks, 2000);
+        run<5, 16>(src, out, blocks, 2000);
+        run<5, 32>(src, out, blocks, 2000);
     }
     return 0;
 }

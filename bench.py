@@ -40,6 +40,17 @@ def one_step(model, x, t, reducer=None):
     return loss
 
 
+def profiled_traffic(kernel: str):
+    """HBM bytes per launch of a kernel family, from the committed PMC pass (profiles/r01_hbm_traffic.json); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
+            doc = json.load(f)
+        fam = kernel.split("/")[0]
+        return round(doc["kernels"][fam]["hbm_bytes_per_launch_corrected"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def host_cores() -> int:
     """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when one is set."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -165,7 +176,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}" if world > 1 else "single",
                        "loss": round(float(loss.detach()), 6)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": profiled_traffic(dom),
+                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes/launch)",
                          "avg_launch_ms": kernels[dom]["avg_ms"], "flops_per_launch": round(fam[dom][2] / fam[dom][0] / 1e9, 3),
                          "all_conv_kernels_tflops": round(all_f / (all_t * 1e-3) / 1e12, 2),
                          "conv_kernel_share_of_step": round(all_t / (elapsed * 1e3), 3),

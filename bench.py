@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=96)
+    ap.add_argument("--force-dp", action="store_true", help="run the bucketed all-reduce path even with one rank (path rehearsal)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -111,9 +112,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dp
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)          # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)          # nccl == RCCL on ROCm
 
     import convkan_amd
     from convkan_amd import ops
@@ -121,17 +125,17 @@ def main():
 
     model = build_model(device)
     reducer = None
-    if world > 1:
+    if use_dist:
         from convkan_amd.parallel import BucketedGradReducer
         for p in model.parameters():                               # identical replicas (same seed); make it explicit
             dist.broadcast(p.data, 0)
-        reducer = BucketedGradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20)
+        reducer = BucketedGradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20, always_reduce=args.force_dp)
     g = torch.Generator(device=device).manual_seed(1 + rank)
     x = torch.randn(args.batch, 3, 32, 32, device=device, generator=g)
     t = torch.randint(0, 10, (args.batch,), device=device, generator=g)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +151,7 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     if rank == 0:
         print(f"[bench] {args.steps} steps in {elapsed:.3f}s on {world} GPU(s)", file=sys.stderr, flush=True)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -188,7 +192,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

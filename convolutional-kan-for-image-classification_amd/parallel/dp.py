@@ -39,8 +39,9 @@ class BucketedGradReducer:
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 96 << 20,
-                 group: Optional[dist.ProcessGroup] = None):
+                 group: Optional[dist.ProcessGroup] = None, always_reduce: bool = False):
         self.group = group
+        self.always_reduce = always_reduce          # run the collective even in a 1-rank group (exercises the path)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         plist = [p for p in params if p.requires_grad]
         self.buckets: List[_Bucket] = []
@@ -69,7 +70,7 @@ class BucketedGradReducer:
             self._launch(b)
 
     def _launch(self, b: _Bucket):
-        if self.world == 1:
+        if self.world == 1 and not self.always_reduce:
             return
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream(b.flat.device))

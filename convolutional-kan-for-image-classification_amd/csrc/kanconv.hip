@@ -41,7 +41,8 @@ struct DevGeom {
 __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
 // ============================================================================ pack / unpack
-// Packed forward layout: the GEMM depth axis is cut into chunks of IPC "items" (item = (c, tap)), each item owning
+// Packed forward layout: the GEMM depth axis is cut into chunks of IPC "items" (item = tap*C + c, TAP-MAJOR so that a
+// whole LDS step belongs to one or two taps and can be skipped when the tap is structurally zero), each item owning
 // P consecutive rows (its planes); a chunk is KC = even(IPC*P) rows, so that one LDS step of the forward kernel is
 // exactly IPC whole items:   k(item, p) = (item / IPC) * KC + (item % IPC) * P + p.
 // The weight-gradient kernel uses the same formula with IPC = 1, KC = P (flat, no padding).
@@ -54,7 +55,7 @@ __device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
     int cq = j / q.T, tap = j - cq * q.T;
     int c = src_kind == 0 ? cq : cq / q.nb;
     int p = src_kind == 0 ? 0 : q.hb + (cq - c * q.nb);
-    int item = c * q.T + tap;
+    int item = tap * q.C + c;                         // tap-major: all channels of a tap are contiguous in the depth axis
     int chunk = item / q.IPC;
     return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
 }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, f
 }
 
 // Backward-data weight layout, derived from the forward one by a per-tap tiled transpose:
-//   wd[(tap * Opad16 + o)][ct * 128 + half * 64 + cl * P + p] = wp[k((c*T+tap), p)][o],
+//   wd[(tap * Opad16 + o)][ct * 128 + half * 64 + cl * P + p] = wp[k((tap*C+c), p)][o],
 //   c = (ct*2 + half) * CH + cl,  CH = 64 / P whole channels per 64-column half
 // i.e. the depth axis (tap, o) is the row, and the 128 columns of one channel tile are contiguous and 16-B aligned.
 // Columns >= CH*P of a half and rows o >= O are zero.
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
         if (col < ncol) {
             int hf = col >> 6, w = col & 63, cl = w / q.P, p = w - cl * q.P, c = hf * CH + cl;
             if (cl < CH && c < q.C && o < q.O) {
-                int item = c * q.T + tap, chunk = item / q.IPC;
+                int item = tap * q.C + c, chunk = item / q.IPC;
                 v = wp[(size_t)(chunk * q.KC + (item - chunk * q.IPC) * q.P + p) * q.Opad + o];
             }
         }
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;                                          // scalar
             const int item = ch * IPC + il;
-            const int c = item / T, tap = item - c * T;
+            const int tap = item / g.C, c = item - tap * g.C;                      // tap-major depth order
             const int r = tap / g.kw, t = tap - r * g.kw;
             const int dr = r * g.dh, dt = t * g.dw;
             const int hi = hi0 + dr, wi = wi0 + dt;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     for (int i = tid; i < n_items; i += NT) {
         int item = item_first + i, v = -1;
         if (item < NI) {
-            int c = item / T, tap = item - c * T, r = tap / g.kw, t = tap - r * g.kw;
+            int tap = item / g.C, c = item - tap * g.C, r = tap / g.kw, t = tap - r * g.kw;
             v = c | (r << 16) | (t << 24);
         }
         sItem[i] = v;

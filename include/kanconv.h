@@ -84,7 +84,7 @@ const char* kan_last_error(void);
 int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
 
 /* Pack the reference-layout weights of one group into the GEMM layouts of the kernels:
- *   wp (forward):   wp[k(item,p)][o],  item = c*T + tap, T = kh*kw,
+ *   wp (forward):   wp[k(item,p)][o],  item = tap*C + c (tap-major), T = kh*kw,
  *                   k = (item / IPC)*KC + (item % IPC)*P + p;  plane p = 0 is the base branch
  *                   (if any), planes hb.. are basis k = p - hb;  plan.packed_weight_bytes.
  *   wd (bwd-data):  optional (NULL to skip), plan.bwd_data_weight_bytes:
@@ -117,7 +117,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
                       float* dx, float* dxn,
                       const KanGeom* geom, const KanBasis* basis, void* stream);
 
-/* Gradient w.r.t. the weights in the FLAT packed layout dwp[(c*T+tap)*P + p][o]
+/* Gradient w.r.t. the weights in the FLAT packed layout dwp[(tap*C+c)*P + p][o]
  * = sum_pixels expanded[k][pixel] * dz[o][pixel], written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
 int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,
                         const KanGeom* geom, const KanBasis* basis, void* stream);

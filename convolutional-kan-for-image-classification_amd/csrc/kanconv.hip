@@ -48,6 +48,28 @@ __device__ __forceinline__ bool tap_alive_out(const DevGeom& g, int hw, int tap)
     const int hi = ho * g.sh - g.ph + r * g.dh, wi = wo * g.sw - g.pw + t * g.dw;
     return (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
 }
+// Split-K ranges must be cut over LIVE steps, or the splits that land on dead taps exit at once while the others
+// run full length.  The step axis is a sequence of `nseg` segments (taps, or pixel positions), segment i starting at
+// step seg_start(i); live_step_pos returns the step at which `target` live steps have gone by (n_steps if past the end).
+template <typename F>
+__device__ __forceinline__ int live_step_pos(unsigned mask, int nseg, int n_steps, int target, F seg_start) {
+    int acc = 0;
+    for (int i = 0; i < nseg; ++i) {
+        if (!((mask >> i) & 1u)) continue;
+        const int s0 = seg_start(i), n = min(seg_start(i + 1), n_steps) - s0;
+        if (target < acc + n) return s0 + (target - acc);
+        acc += n;
+    }
+    return n_steps;
+}
+template <typename F>
+__device__ __forceinline__ int live_step_count(unsigned mask, int nseg, int n_steps, F seg_start) {
+    int acc = 0;
+    for (int i = 0; i < nseg; ++i)
+        if ((mask >> i) & 1u) acc += min(seg_start(i + 1), n_steps) - seg_start(i);
+    return acc;
+}
+
 __device__ __forceinline__ bool tap_alive_in(const DevGeom& g, int hw, int tap) {       // input position hw, transposed tap
     const int h = hw / g.W, w = hw - h * g.W, r = tap / g.kw, t = tap - r * g.kw;
     const int hn = h + g.ph - r * g.dh, wn = w + g.pw - t * g.dw;
@@ -159,6 +181,26 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
     for (int i = 0; i < 4; ++i) {                                   // write wd along the columns (contiguous)
         int o = o0 + ty + 8 * i, col = col0 + tx;
         if (o < Opad32 && col < ncol) wd[((size_t)tap * Opad32 + o) * ncol + col] = tile[tx][ty + 8 * i];
+    }
+}
+
+// ============================================================================ position-major copy
+// dst[(c*HW + i)*B + b] = src[b*bstride + c*HW + i]: the small-plane kernels gather "one position of many images" per
+// wave; in NCHW those are 4-byte reads C*HW*4 bytes apart, in this copy they are contiguous.  32x32 LDS transpose.
+__global__ __launch_bounds__(256) void k_position_major(const float* __restrict__ src, float* __restrict__ dst, int B, int CHW, long long bstride) {
+    __shared__ float tile[32][33];
+    const int e0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = b0 + ty + 8 * i, e = e0 + tx;
+        tile[ty + 8 * i][tx] = (b < B && e < CHW) ? src[(size_t)b * bstride + e] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = e0 + ty + 8 * i, b = b0 + tx;
+        if (e < CHW && b < B) dst[(size_t)e * B + b] = tile[tx][ty + 8 * i];
     }
 }
 
@@ -291,8 +333,10 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
         else { b = my_px / HoWo; hw = my_px - b * HoWo; }
         int ho = hw / g.Wo, wo = hw - ho * g.Wo;
         hi0 = ho * g.sh - g.ph; wi0 = wo * g.sw - g.pw;
-        pbase = b * (int)g.xbs + hi0 * g.W + wi0;
+        // position-major tiles read the [C*H*W][B] copy of x: element (c,hi,wi) of image b sits at (c*HW+hi*W+wi)*B + b
+        pbase = g.pix_major ? (hi0 * g.W + wi0) * g.B + b : b * (int)g.xbs + hi0 * g.W + wi0;
     }
+    const int estride = g.pix_major ? g.B : 1;               // element stride of the (c,hi,wi) index
     const bool same_in = (KIND != KAN_BASIS_RBF) || (x == xn);     // only FastKAN evaluates its basis on a second tensor
     const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes);
     const int wv = wave;
@@ -313,7 +357,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
             const int dr = r * g.dh, dt = t * g.dw;
             const int hi = hi0 + dr, wi = wi0 + dt;
             const bool inb = il < IPC && pv && item < NI && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-            const unsigned off = inb ? (unsigned)(pbase + (c * HW + dr * g.W + dt)) * 4u : KAN_OOB;
+            const unsigned off = inb ? (unsigned)(pbase + (c * HW + dr * g.W + dt) * estride) * 4u : KAN_OOB;
             xa[u] = buf_load(x_rs, off);
             xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
             inb_mask |= (inb ? 1u : 0u) << u;
@@ -346,8 +390,8 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int ch0 = blockIdx.z * chunks_per_split;
-    const int ch1 = min(n_chunks, ch0 + chunks_per_split);
+    int ch0 = blockIdx.z * chunks_per_split;
+    int ch1 = min(n_chunks, ch0 + chunks_per_split);
     // taps that are alive for at least one pixel position of this tile (all of them unless the tile is position-major)
     unsigned tapmask = 0xffffffffu;
     if (g.pix_major) {
@@ -355,6 +399,16 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
         const int hwA = px_tile0 / g.B, hwB = min(px_tile0 + TP - 1, Mtot - 1) / g.B;
         for (int hw = hwA; hw <= hwB; ++hw)
             for (int tap = 0; tap < T; ++tap) tapmask |= (tap_alive_out(g, hw, tap) ? 1u : 0u) << tap;
+        // cut this tile's split ranges over its live steps (segment = tap, starting at the step holding its first item)
+        auto seg = [&](int tap) { return (tap * g.C + IPC - 1) / IPC; };
+        // this tile's own split count: ~chunks_per_split live steps each; surplus workgroups only store a zero slab
+        const int L = live_step_count(tapmask, T, n_chunks, seg);
+        const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));
+        if ((int)blockIdx.z >= S) { ch0 = ch1 = n_chunks; }
+        else {
+            ch0 = blockIdx.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blockIdx.z / S), seg);
+            ch1 = (int)blockIdx.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blockIdx.z + 1) / S), seg);
+        }
     }
     // first step >= ch that touches a live tap (a step holds IPC consecutive items of the tap-major depth axis)
     auto next_live = [&](int ch) -> int {
@@ -443,8 +497,10 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         else { pb = my_px / HW; hw = my_px - pb * HW; }
         ph_ = hw / g.W; pw_ = hw - ph_ * g.W;
     }
+    // `dz` is the NCHW tensor, or (position-major tiles) its [O*Ho*Wo][B] copy: element (o,ho,wo) of image b at (o*HoWo+ho*Wo+wo)*B + b
     const kan_rsrc dz_rs = make_rsrc(dz, dz_bytes);
-    const unsigned dz_img = (unsigned)pb * (unsigned)g.ybs;
+    const unsigned dz_img = g.pix_major ? (unsigned)pb : (unsigned)pb * (unsigned)g.ybs;
+    const unsigned zstride = g.pix_major ? (unsigned)g.B : 1u;
     const int wv = wave;
 
     // On gfx950 the fp32 MFMA shares the vector ALU: every VALU instruction in this loop costs ~4.5 cycles of matrix
@@ -452,7 +508,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     // of a tap, per-lane offsets are precomputed, and the per-step parts ride in scalar registers.
     int cur_tap = -1; unsigned base = KAN_OOB;                // gather offset of this thread's pixel for cur_tap
     const unsigned wlane = (unsigned)((lane >> 5) * ncol + (lane & 31) * 4) * 4u;      // byte offset of this lane in a 2-row weight block
-    const unsigned row_bytes = (unsigned)HoWo * 4u;
+    const unsigned row_bytes = (unsigned)HoWo * zstride * 4u;
     const bool o_full = (n_ob * KD == g.O);                   // no ragged last output block
 
     // issue(ch, buf): start the async copies of step ch into LDS buffer `buf`: the gathered dz tile (16 outputs x 128
@@ -469,7 +525,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
                 ok = ok && ho * g.sh == hn && wo * g.sw == wn;
             }
             ok = ok && ho < g.Ho && wo < g.Wo;
-            base = ok ? (dz_img + (unsigned)(ho * g.Wo + wo)) * 4u : KAN_OOB;
+            base = ok ? (dz_img + (unsigned)(ho * g.Wo + wo) * zstride) * 4u : KAN_OOB;
         }
         float* dW = smem + buf * (2 * KD * 128);
         float* dG = dW + KD * 128 + (wv & 1) * 64;
@@ -502,14 +558,23 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int ch0 = blockIdx.z * chunks_per_split;
-    const int ch1 = min(n_chunks, ch0 + chunks_per_split);
+    int ch0 = blockIdx.z * chunks_per_split;
+    int ch1 = min(n_chunks, ch0 + chunks_per_split);
     unsigned tapmask = 0xffffffffu;                        // taps alive for some pixel position of this tile
     if (g.pix_major) {
         tapmask = 0;
+        const int T = g.kh * g.kw;
         const int hwA = px_tile0 / g.B, hwB = min(px_tile0 + TP - 1, Min - 1) / g.B;
         for (int hw = hwA; hw <= hwB; ++hw)
-            for (int tap = 0; tap < g.kh * g.kw; ++tap) tapmask |= (tap_alive_in(g, hw, tap) ? 1u : 0u) << tap;
+            for (int tap = 0; tap < T; ++tap) tapmask |= (tap_alive_in(g, hw, tap) ? 1u : 0u) << tap;
+        auto seg = [&](int tap) { return tap * n_ob; };     // steps are (tap, output block)
+        const int L = live_step_count(tapmask, T, n_chunks, seg);
+        const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));   // ~chunks_per_split live steps each
+        if ((int)blockIdx.z >= S) { ch0 = ch1 = n_chunks; }
+        else {
+            ch0 = blockIdx.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blockIdx.z / S), seg);
+            ch1 = (int)blockIdx.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blockIdx.z + 1) / S), seg);
+        }
     }
     auto next_live = [&](int ch) -> int {                  // steps are (tap, output block): skip dead taps whole
         while (ch < ch1) {
@@ -631,19 +696,23 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     int s_b = 0, s_hi0 = 0, s_wi0 = 0; bool s_pv = false;    // pixel decode of the staged step (for units beyond UPF)
     const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes), dz_rs = make_rsrc(dz, dz_bytes);
     const bool o_full = o_tile0 + TO <= g.O;                   // no ragged output tile
-    const unsigned row_bytes = (unsigned)HoWo * 4u;
+    const unsigned row_bytes = (unsigned)HoWo * (g.pix_major ? (unsigned)g.B : 1u) * 4u;
 
     auto unit_addr = [&](int it, int b, int hi0, int wi0, bool pv, unsigned& idx) -> bool {     // idx: element offset (32 bit)
         const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
         const int hi = hi0 + r * g.dh, wi = wi0 + t * g.dw;
-        idx = (unsigned)(b * (int)g.xbs + c * HW + hi * g.W + wi);
+        idx = g.pix_major ? (unsigned)((c * HW + hi * g.W + wi) * g.B + b) : (unsigned)(b * (int)g.xbs + c * HW + hi * g.W + wi);
         return pv && it >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
     };
     auto issue = [&](int ch) {
         const int px = ch * KPX + pl;
         const bool pv = px < Mtot;
         int b, hw, ho, wo;
-        if (g.howo_shift >= 0) {                               // uniform: power-of-two planes decode by shifts
+        if (g.pix_major) {                                     // uniform: pixel index = position * B + image
+            if (g.b_shift >= 0) { hw = px >> g.b_shift; b = px & (g.B - 1); }
+            else { hw = px / g.B; b = px - hw * g.B; }
+            ho = hw / g.Wo; wo = hw - ho * g.Wo;
+        } else if (g.howo_shift >= 0) {                        // uniform: power-of-two planes decode by shifts
             b = px >> g.howo_shift; hw = px & (HoWo - 1);
             ho = hw >> g.wo_shift; wo = hw & (g.Wo - 1);
         } else {
@@ -662,7 +731,9 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
             xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
             inb_mask |= (inb ? 1u : 0u) << u;
         }
-        const unsigned zbase = pv ? ((unsigned)b * (unsigned)g.ybs + (unsigned)hw + (unsigned)(o_tile0 + il0) * (unsigned)HoWo) * 4u : KAN_OOB;
+        const unsigned zbase = !pv ? KAN_OOB
+            : g.pix_major ? (((unsigned)(o_tile0 + il0) * (unsigned)HoWo + (unsigned)hw) * (unsigned)g.B + (unsigned)b) * 4u
+                          : ((unsigned)b * (unsigned)g.ybs + (unsigned)hw + (unsigned)(o_tile0 + il0) * (unsigned)HoWo) * 4u;
         if (o_full) {                                          // uniform: the per-output part of the offset rides in a scalar
 #pragma unroll
             for (int n = 0; n < ZL; ++n)
@@ -706,15 +777,42 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int ch0 = blockIdx.z * chunks_per_split;
-    const int ch1 = min(n_chunks, ch0 + chunks_per_split);
-    issue(ch0);
+    int ch0 = blockIdx.z * chunks_per_split;
+    int ch1 = min(n_chunks, ch0 + chunks_per_split);
+    // positions whose pixels give this row tile a non-zero contribution: a row tile spans one or two taps of the
+    // tap-major depth axis, and a tap is structurally zero at some output positions (position-major steps only)
+    unsigned hwmask = 0xffffffffu;
+    if (g.pix_major) {
+        hwmask = 0;
+        const int tapA = item_first / g.C, tapB = min(item_first + n_items - 1, NI - 1) / g.C;
+        for (int hw = 0; hw < HoWo; ++hw)
+            for (int tap = tapA; tap <= tapB; ++tap) hwmask |= (tap_alive_out(g, hw, tap) ? 1u : 0u) << hw;
+        auto seg = [&](int hw) { return (hw * g.B + KPX - 1) / KPX; };   // segment = position: its first whole step
+        const int L = live_step_count(hwmask, HoWo, n_chunks, seg);
+        const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));   // ~chunks_per_split live steps each
+        if ((int)blockIdx.z >= S) { ch0 = ch1 = n_chunks; }
+        else {
+            ch0 = blockIdx.z == 0 ? 0 : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * blockIdx.z / S), seg);
+            ch1 = (int)blockIdx.z == S - 1 ? n_chunks : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * (blockIdx.z + 1) / S), seg);
+        }
+    }
+    auto next_live = [&](int ch) -> int {
+        if (!g.pix_major) return ch;
+        while (ch < ch1) {
+            const int hwA = (ch * KPX) / g.B, hwB = min(ch * KPX + KPX - 1, Mtot - 1) / g.B;
+            if (((hwmask >> hwA) | (hwmask >> hwB)) & 1u) return ch;
+            ch = max(ch + 1, ((hwB + 1) * g.B) / KPX);       // first step of the next position
+        }
+        return ch1;
+    };
+    int ch = next_live(ch0);
+    if (ch < ch1) issue(ch);
     const int ar = w_r * 64 + (lane & 31), bo = w_c * 64 + (lane & 31), kh2 = lane >> 5;
-    for (int ch = ch0; ch < ch1; ++ch) {
-        const int cur = (ch - ch0) & 1;
+    for (int cur = 0; ch < ch1; cur ^= 1) {
         stage(cur);
         __syncthreads();
-        if (ch + 1 < ch1) issue(ch + 1);
+        ch = next_live(ch + 1);
+        if (ch < ch1) issue(ch);
         const float* cE = sE + cur * (KPX * LDE) + MRG;
         const float* cZ = sZ + cur * (KPX * LDZ);
 #pragma unroll
@@ -928,13 +1026,18 @@ DevGeom dev_geom(const KanGeom* g) {
     d.b_shift = log2_exact(g->B);
     return d;
 }
-// Position-major pixel order (and with it tap skipping) trades coalescing for skipped work: lanes then walk images
-// (stride C*H*W) instead of a plane.  Measured on KAN-VGG11: 2x2 planes (56 % dead products) gain 27-40 %, 4x4 planes
-// (31 % dead) LOSE 5-30 % to the strided 4-byte gathers -- so only planes of <= 4 positions take this path for now
-// (a position-major copy of the small activations would lift that).  Masks are 32-bit.
-bool want_pix_major(const KanGeom* g, bool input_side) {
-    const int plane = input_side ? g->H * g->W : g->Ho * g->Wo;
-    return plane <= 4 && g->kh * g->kw <= 32 && (g->ph > 0 || g->pw > 0) && g->B >= 16;
+// Position-major pixel order (and with it tap skipping) is offered on small padded planes (<= 16 positions: 31 % of
+// the products are dead on 4x4, 56 % on 2x2).  Lanes then walk images, so the kernels must be given the [C*H*W][B]
+// copies of their gathered inputs (kan_position_major); without a copy they stay on the image-major path (on NCHW the
+// strided 4-byte gathers cost more than 4x4 skipping saves).  Masks are 32-bit.  Not for FastKAN (second input tensor).
+// Measured on KAN-VGG11 (bs 256): the weight-gradient kernel gains 27 % on 4x4 planes and 65 % on 2x2; forward and
+// bwd-data gain 40-60 % on 2x2 but nothing on 4x4 (their step latency, not the step count, sets the time there), so
+// they take the position-major path only up to 4 positions.
+enum { PM_FWD = 0, PM_BWD_DATA = 1, PM_BWD_WEIGHT = 2 };
+bool want_pix_major(const KanGeom* g, const KanBasis* b, int which) {
+    const int plane = which == PM_BWD_DATA ? g->H * g->W : g->Ho * g->Wo;
+    const int limit = which == PM_BWD_WEIGHT ? 16 : 4;
+    return b->kind != KAN_BASIS_RBF && plane <= limit && g->kh * g->kw <= 32 && (g->ph > 0 || g->pw > 0) && g->B >= 16;
 }
 
 DevBasis dev_basis(const KanBasis* b) {
@@ -991,6 +1094,58 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8);
     return c;
 }
+// With dead-tap skipping the tiles of one launch carry 4/9 ... 9/9 of the nominal work depending on their pixel
+// position (or tap, for the weight gradient).  Each tile therefore gets its own split count ceil(live steps / target)
+// so that every workgroup runs ~`target` live steps, and the target is chosen on the host by the same round model as
+// pick_splits, evaluated on the true per-class workgroup counts (a 1088-workgroup grid would run two rounds).
+// (Oversubscribing 4x with small equal splits instead was measured 15-40 % slower.)
+struct LiveClass { long long tiles; int live_steps; };           // tiles sharing one live-step count
+int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, int* max_splits) {
+    const long long SLOTS = 1024;
+    int hi = 1;
+    for (int i = 0; i < ncls; ++i) if (cls[i].live_steps > hi) hi = cls[i].live_steps;
+    int best = hi; long long best_cost = -1; int best_ms = 1;
+    for (int t = min_steps < hi ? min_steps : hi; t <= hi; ++t) {
+        long long wgs = 0; int ms = 1;
+        for (int i = 0; i < ncls; ++i) {
+            const int sp = cls[i].live_steps > 0 ? ceil_div(cls[i].live_steps, t) : 1;
+            wgs += cls[i].tiles * sp;
+            if (sp > ms) ms = sp;
+        }
+        const long long rounds = (wgs + SLOTS - 1) / SLOTS;
+        const long long cost = rounds * (t + 6) + ms / 6;
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; best_ms = ms; }
+    }
+    *max_splits = best_ms;
+    return best;
+}
+int live_taps_out(const KanGeom* g, int hw) {
+    int n = 0;
+    for (int tap = 0; tap < g->kh * g->kw; ++tap) {
+        const int r = tap / g->kw, t = tap % g->kw, ho = hw / g->Wo, wo = hw % g->Wo;
+        const int hi = ho * g->sh - g->ph + r * g->dh, wi = wo * g->sw - g->pw + t * g->dw;
+        n += (hi >= 0 && hi < g->H && wi >= 0 && wi < g->W);
+    }
+    return n;
+}
+int live_taps_in(const KanGeom* g, int hw) {
+    int n = 0;
+    for (int tap = 0; tap < g->kh * g->kw; ++tap) {
+        const int r = tap / g->kw, t = tap % g->kw, h = hw / g->W, w = hw % g->W;
+        const int hn = h + g->ph - r * g->dh, wn = w + g->pw - t * g->dw;
+        n += (hn >= 0 && wn >= 0 && hn % g->sh == 0 && wn % g->sw == 0 && hn / g->sh < g->Ho && wn / g->sw < g->Wo);
+    }
+    return n;
+}
+int live_positions_for_tap(const KanGeom* g, int tap) {
+    int n = 0;
+    for (int hw = 0; hw < g->Ho * g->Wo; ++hw) {
+        const int r = tap / g->kw, t = tap % g->kw, ho = hw / g->Wo, wo = hw % g->Wo;
+        const int hi = ho * g->sh - g->ph + r * g->dh, wi = wo * g->sw - g->pw + t * g->dw;
+        n += (hi >= 0 && hi < g->H && wi >= 0 && wi < g->W);
+    }
+    return n;
+}
 struct BdCfg { int CH, tiles_c, tiles_p, n_ob, Opad32, chunks, splits; };   // Opad32: rows per tap of wd (multiple of 32)
 BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     BdCfg c;
@@ -1039,6 +1194,27 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_splits = fwd_cfg(g, *pl).splits;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = bw_cfg(g, *pl).splits;
+    pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
+    pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
+    pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
+    if (want_pix_major(g, b, PM_FWD)) {          // forward: one class per output position; a tap holds C/IPC steps
+        LiveClass cls[16]; const int plane = g->Ho * g->Wo; FwdCfg fc = fwd_cfg(g, *pl);
+        const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o;
+        for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
+        pl->fwd_target = pick_target_steps(cls, plane, 8, &pl->fwd_splits);
+    }
+    if (want_pix_major(g, b, PM_BWD_WEIGHT)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
+        LiveClass cw[32]; BwCfg wc = bw_cfg(g, *pl);
+        const long long tiles_per_tap = (long long)ceil_div((long long)g->C * pl->P, wc.TR) * wc.tiles_o;
+        for (int tap = 0; tap < T; ++tap) cw[tap] = LiveClass{tiles_per_tap, live_positions_for_tap(g, tap) * ceil_div(g->B, 16)};
+        pl->bwd_weight_target = pick_target_steps(cw, T, 16, &pl->bwd_weight_splits);
+    }
+    if (want_pix_major(g, b, PM_BWD_DATA)) {     // bwd-data: one class per input position; a tap holds n_ob steps
+        LiveClass cls[16]; const int plane = g->H * g->W;
+        const long long tiles_per_pos = (long long)ceil_div(g->B, 128) * bd.tiles_c;
+        for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_in(g, hw) * bd.n_ob};
+        pl->bwd_data_target = pick_target_steps(cls, plane, 8, &pl->bwd_data_splits);
+    }
     return 0;
 }
 
@@ -1134,17 +1310,26 @@ int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const Ka
     return launch_ok("unpack");
 }
 
-int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, const KanGeom* g, const KanBasis* b, void* stream) {
+int kan_position_major(const float* src, float* dst, int B, int Cn, int HW, long long bstride, void* stream) {
+    if (!src || !dst || B < 1 || Cn < 1 || HW < 1) return fail("bad position_major arguments");
+    dim3 grid(ceil_div((long long)Cn * HW, 32), ceil_div(B, 32));
+    hipLaunchKernelGGL(k_position_major, grid, dim3(256), 0, (hipStream_t)stream, src, dst, B, Cn * HW, bstride);
+    return launch_ok("position_major");
+}
+
+int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, const KanGeom* g, const KanBasis* b, const float* x_pm,
+                 void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!x || !xn || !wp || !z) return fail("null tensor pointer");
     FwdCfg c = fwd_cfg(g, pl);
     DevGeom dg = dev_geom(g);
-    dg.pix_major = want_pix_major(g, false) ? 1 : 0;
+    dg.pix_major = (x_pm && want_pix_major(g, b, PM_FWD)) ? 1 : 0;
+    if (dg.pix_major) { x = x_pm; xn = x_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(c.tiles_p, c.tiles_o, c.splits);
-    int cps = ceil_div(c.chunks, c.splits);
+    dim3 grid(c.tiles_p, c.tiles_o, pl.fwd_splits);          // always the plan's slab count: the consumer sums exactly that many
+    int cps = dg.pix_major ? pl.fwd_target : ceil_div(c.chunks, pl.fwd_splits);
 #define KAN_FWD(KIND, WO, WP, KCV) KAN_FWD2(KIND, 0, WO, WP, KCV)
 #define KAN_FWD2(KIND, FAST, WO, WP, KCV) \
     hipLaunchKernelGGL((k_conv_fwd<KIND, FAST, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4))
@@ -1168,18 +1353,19 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
 }
 
 int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn,
-                      const KanGeom* g, const KanBasis* b, void* stream) {
+                      const KanGeom* g, const KanBasis* b, const float* dz_pm, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !wd || !dx) return fail("null tensor pointer");
     if (!dxn && x != xn) return fail("dxn is required when xn != x");
     BdCfg c = bd_cfg(g, pl);
     DevGeom dg = dev_geom(g);
-    dg.pix_major = want_pix_major(g, true) ? 1 : 0;
+    dg.pix_major = (dz_pm && want_pix_major(g, b, PM_BWD_DATA)) ? 1 : 0;
+    if (dg.pix_major) dz = dz_pm;
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(c.tiles_p, c.tiles_c, c.splits);
-    int cps = ceil_div(c.chunks, c.splits);
+    dim3 grid(c.tiles_p, c.tiles_c, pl.bwd_data_splits);
+    int cps = dg.pix_major ? pl.bwd_data_target : ceil_div(c.chunks, pl.bwd_data_splits);
 #define KAN_BD(KIND) \
     hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4))
     if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
@@ -1189,16 +1375,19 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     return launch_ok("conv_bwd_data");
 }
 
-int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp, const KanGeom* g, const KanBasis* b, void* stream) {
+int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp, const KanGeom* g, const KanBasis* b,
+                        const float* x_pm, const float* dz_pm, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !dwp) return fail("null tensor pointer");
     BwCfg c = bw_cfg(g, pl);
     DevGeom dg = dev_geom(g);
+    dg.pix_major = (x_pm && dz_pm && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
+    if (dg.pix_major) { x = x_pm; xn = x_pm; dz = dz_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(c.tiles_r, c.tiles_o, c.splits);
-    int cps = ceil_div(c.chunks, c.splits);
+    dim3 grid(c.tiles_r, c.tiles_o, pl.bwd_weight_splits);
+    int cps = dg.pix_major ? pl.bwd_weight_target : ceil_div(c.chunks, pl.bwd_weight_splits);
 #define KAN_BW(KIND, WR, WC) KAN_BW2(KIND, 0, WR, WC)
 #define KAN_BW2(KIND, FAST, WR, WC) \
     hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4))

@@ -127,8 +127,16 @@ def _tile_tag(plan) -> str:
 
 
 # --------------------------------------------------------------------------------------- raw stages
+def _position_major(t: torch.Tensor, ch_off: int, Cn: int) -> torch.Tensor:
+    """[Cn*H*W][B] copy of channels [ch_off, ch_off+Cn) of an NCHW tensor (kan_position_major)."""
+    B, Ct, H, W = t.shape
+    out = torch.empty(Cn * H * W * B, device=t.device, dtype=torch.float32)
+    L.check(L.load().kan_position_major(_ptr(t, ch_off * H * W), _ptr(out), B, Cn, H * W, Ct * H * W, _stream(t)), "kan_position_major")
+    return out
+
+
 def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True):
-    """Returns (z_slabs [S,B,O,Ho,Wo], bwd-data weight layout per group (or None), geom, basis, plan)."""
+    """Returns (z_slabs [S,B,O,Ho,Wo], per-group (bwd-data weight layout or None, position-major x or None), geom, basis, plan)."""
     lib = L.load()
     B, Ct, H, W = x.shape
     G = spec.groups
@@ -144,10 +152,11 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
         wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=x.device, dtype=torch.float32) if need_dgrad else None
         L.check(lib.kan_pack_weights(_ptr(w_base[g]), _ptr(w_basis[g]), _ptr(wp), _ptr(wd), C.byref(geom), C.byref(basis), st),
                 "kan_pack_weights")
+        x_pm = _position_major(x, g * Cg, Cg) if (plan.x_pm_wanted and xn is None) else None
         _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
                 lambda: lib.kan_conv_fwd(_ptr(x, g * Cg * H * W), _ptr(xn if xn is not None else x, g * Cg * H * W), _ptr(wp),
-                                         _ptr(z, g * Og * Ho * Wo), C.byref(geom), C.byref(basis), st))
-        packed.append(wd)
+                                         _ptr(z, g * Og * Ho * Wo), C.byref(geom), C.byref(basis), _ptr(x_pm), st))
+        packed.append((wd, x_pm))
     return z, packed, geom, basis, plan
 
 
@@ -166,12 +175,15 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     xs = xn if xn is not None else x
     dw_base: List[Optional[torch.Tensor]] = [None] * G
     dw_basis: List[Optional[torch.Tensor]] = [None] * G
+    dz_pm = [None] * G
+    if plan.dz_pm_wanted and xn is None:
+        dz_pm = [_position_major(dz, g * Og, Og) for g in range(G)]
     if need_w:
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
         for g in range(G):
             _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
                     lambda: lib.kan_conv_bwd_weight(_ptr(dz, g * Og * Ho * Wo), _ptr(x, g * Cg * H * W), _ptr(xs, g * Cg * H * W),
-                                                    _ptr(dwp), C.byref(geom), C.byref(basis), st))
+                                                    _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(packed[g][1]), _ptr(dz_pm[g]), st))
             if spec.has_base:
                 dw_base[g] = torch.empty((Og, Cg, kh, kw), device=x.device, dtype=torch.float32)
             dw_basis[g] = torch.empty((Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
@@ -185,9 +197,9 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         for g in range(G):
             off = g * Cg * H * W
             _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
-                    lambda: lib.kan_conv_bwd_data(_ptr(dz, g * Og * Ho * Wo), _ptr(x, off), _ptr(xs, off), _ptr(packed[g]),
+                    lambda: lib.kan_conv_bwd_data(_ptr(dz, g * Og * Ho * Wo), _ptr(x, off), _ptr(xs, off), _ptr(packed[g][0]),
                                                   _ptr(dxs, off), _ptr(dxns, off) if separate else C.c_void_p(0),
-                                                  C.byref(geom), C.byref(basis), st))
+                                                  C.byref(geom), C.byref(basis), _ptr(dz_pm[g]), st))
         dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
     return dx, dxn, dw_base, dw_basis
 
@@ -199,6 +211,14 @@ def _sum_slabs(slabs: torch.Tensor, B: int, Cn: int, HW: int) -> torch.Tensor:
     out = torch.empty_like(slabs[0])
     L.check(L.load().kan_slab_reduce(_ptr(slabs), slabs.shape[0], slabs[0].numel(), _ptr(out), B, Cn, HW, Cn * HW, _stream(slabs)),
             "kan_slab_reduce")
+    return out
+
+
+def _unflatten(layout, tensors):
+    """Inverse of the save_for_backward flattening of the per-group (wd, x_pm) pairs."""
+    out, it = [], iter(tensors)
+    for has_wd, has_xp in layout:
+        out.append((next(it) if has_wd else None, next(it) if has_xp else None))
     return out
 
 
@@ -220,8 +240,9 @@ class _KanConv(torch.autograd.Function):
         with torch.cuda.device(x.device):
             z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis, need_dgrad)
             z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
-        ctx.spec, ctx.has_xn, ctx.has_wd = spec, xn is not None, need_dgrad
-        ctx.save_for_backward(x, *([xn] if xn is not None else []), *(packed if need_dgrad else []))
+        ctx.spec, ctx.has_xn = spec, xn is not None
+        ctx.layout = [(wd is not None, xp is not None) for wd, xp in packed]
+        ctx.save_for_backward(x, *([xn] if xn is not None else []), *[t for pair in packed for t in pair if t is not None])
         return z
 
     @staticmethod
@@ -229,7 +250,7 @@ class _KanConv(torch.autograd.Function):
         saved = ctx.saved_tensors
         x = saved[0]
         xn = saved[1] if ctx.has_xn else None
-        packed = saved[1 + int(ctx.has_xn):] if ctx.has_wd else [None] * ctx.spec.groups
+        packed = _unflatten(ctx.layout, list(saved[1 + int(ctx.has_xn):]))
         need_x, need_xn = ctx.needs_input_grad[1], ctx.has_xn and ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[3:])
         with torch.cuda.device(x.device):
@@ -270,8 +291,9 @@ class _KanConvInPrelu(torch.autograd.Function):
                                                    _ptr(prelus[g]), _ptr(y, off), _ptr(mean, g * B * Og), _ptr(rstd, g * B * Og),
                                                    B, Og, HW, Ot * HW, eps, st), "kan_instnorm_prelu_fwd")
         z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
-        ctx.spec, ctx.flags, ctx.has_wd = spec, (use_affine, use_prelu), need_dgrad
-        ctx.save_for_backward(x, z, mean, rstd, *(packed if need_dgrad else []),
+        ctx.spec, ctx.flags = spec, (use_affine, use_prelu)
+        ctx.layout = [(wd is not None, xp is not None) for wd, xp in packed]
+        ctx.save_for_backward(x, z, mean, rstd, *[t for pair in packed for t in pair if t is not None],
                               *[t for t in list(gammas) + list(betas) + list(prelus) if t is not None])
         return y
 
@@ -283,8 +305,8 @@ class _KanConvInPrelu(torch.autograd.Function):
         G = spec.groups
         saved = ctx.saved_tensors
         x, z, mean, rstd = saved[:4]
-        nwd = G if ctx.has_wd else 0
-        packed = saved[4:4 + nwd] if ctx.has_wd else [None] * G
+        nwd = sum(int(a) + int(b) for a, b in ctx.layout)
+        packed = _unflatten(ctx.layout, list(saved[4:4 + nwd]))
         rest = list(saved[4 + nwd:])
         gammas = rest[:G] if use_affine else [None] * G
         betas = rest[G:2 * G] if use_affine else [None] * G

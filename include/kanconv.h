@@ -70,6 +70,9 @@ typedef struct KanPlan {
     int fwd_splits;               /* z is written as fwd_splits partial slabs */
     int bwd_data_splits;          /* dx is written as bwd_data_splits partial slabs */
     int bwd_weight_splits;        /* packed dW is written as bwd_weight_splits partial slabs */
+    int fwd_target, bwd_data_target, bwd_weight_target;   /* position-major launches: live steps per split (0 = n/a) */
+    int x_pm_wanted, dz_pm_wanted;/* small padded planes: pass position-major copies (kan_position_major) of x / dz to
+                                     unlock structural-zero tap skipping; optional, NULL keeps the image-major path */
     long long packed_weight_bytes;    /* Kpad*Opad*4 */
     long long bwd_data_weight_bytes;  /* size of the bwd-data weight layout `wd` */
     long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */
@@ -106,7 +109,12 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
  * z holds plan.fwd_splits slabs of plan.fwd_slab_elems elements; their sum is the result
  * (kan_instnorm_prelu_fwd / kan_slab_reduce consume slabs directly). */
 int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z,
-                 const KanGeom* geom, const KanBasis* basis, void* stream);
+                 const KanGeom* geom, const KanBasis* basis, const float* x_pm, void* stream);
+
+/* dst[(c*HW + i)*B + b] = src[b*bstride + c*HW + i]  (B images, Cn channels of HW pixels): the position-major copy
+ * the conv kernels read on small padded planes, where whole taps are structurally zero for a given output position
+ * (the reference multiplies those zeros: kan_layers.py:239 zero-pads the expanded tensor). */
+int kan_position_major(const float* src, float* dst, int B, int Cn, int HW, long long bstride, void* stream);
 
 /* Gradient w.r.t. the input (autograd of the sites listed at kan_conv_fwd):
  *   dx  = act'(x) * dgrad(dz, W_base)              (base branch)
@@ -115,12 +123,12 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z,
  * plan.bwd_data_splits slabs of plan.bwd_data_slab_elems elements. */
 int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wd,
                       float* dx, float* dxn,
-                      const KanGeom* geom, const KanBasis* basis, void* stream);
+                      const KanGeom* geom, const KanBasis* basis, const float* dz_pm, void* stream);
 
 /* Gradient w.r.t. the weights in the FLAT packed layout dwp[(tap*C+c)*P + p][o]
  * = sum_pixels expanded[k][pixel] * dz[o][pixel], written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
 int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,
-                        const KanGeom* geom, const KanBasis* basis, void* stream);
+                        const KanGeom* geom, const KanBasis* basis, const float* x_pm, const float* dz_pm, void* stream);
 
 /* Sum the dwp slabs and scatter back to the reference layouts (inverse of kan_pack_weights).
  * dw_base may be NULL iff there is no base branch. */

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.KanGeom) == 15 * 4 + 4 + 16          # 15 ints, pad, 2 x int64
     assert ctypes.sizeof(L.KanBasis) == 4 * 4 + 2 * 4 + 32 * 4
-    assert ctypes.sizeof(L.KanPlan) == 9 * 4 + 4 + 5 * 8
+    assert ctypes.sizeof(L.KanPlan) == 14 * 4 + 5 * 8
 
 
 def _plan(C, O, H, k=3, p=1, s=1, B=4, kind=L.BASIS_BSPLINE, nb=8, order=3, act=L.ACT_SILU, table=None):

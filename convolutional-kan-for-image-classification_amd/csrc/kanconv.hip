@@ -412,6 +412,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     }
     // first step >= ch that touches a live tap (a step holds IPC consecutive items of the tap-major depth axis)
     auto next_live = [&](int ch) -> int {
+        if (!g.pix_major) return ch;                       // (keeps the integer divisions below off the common path)
         while (ch < ch1) {
             const int tapA = (ch * IPC) / g.C, tapB = min(ch * IPC + IPC - 1, NI - 1) / g.C;
             if (((tapmask >> tapA) | (tapmask >> tapB)) & 1u) return ch;
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         }
     }
     auto next_live = [&](int ch) -> int {                  // steps are (tap, output block): skip dead taps whole
+        if (!g.pix_major) return ch;
         while (ch < ch1) {
             const int tap = ch / n_ob;
             if ((tapmask >> tap) & 1u) return ch;

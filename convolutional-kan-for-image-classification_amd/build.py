@@ -1,7 +1,9 @@
 """In-tree build of libkanconv.so with hipcc for gfx950 (no JIT cache: the .so travels with the repo)."""
+import fcntl
 import os
 import shutil
 import subprocess
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
@@ -24,9 +26,24 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libkanconv.so")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", os.path.join(_ROOT, "include"),
-           "-I", os.path.join(_HERE, "csrc"), "-o", OUTPUT] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    # several ranks of one node may get here at once: serialise on a lock file, re-check, and publish atomically
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return OUTPUT
+            fd, tmp = tempfile.mkstemp(suffix=".so", dir=_HERE)
+            os.close(fd)
+            cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", os.path.join(_ROOT, "include"),
+                   "-I", os.path.join(_HERE, "csrc"), "-o", tmp] + SOURCES
+            if verbose:
+                print(" ".join(cmd))
+            try:
+                subprocess.run(cmd, check=True)
+                os.replace(tmp, OUTPUT)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUTPUT

@@ -1061,18 +1061,22 @@ DevBasis dev_basis(const KanBasis* b) {
 // runs in ceil(W/1024) rounds and wastes the empty part of the last one (1184 workgroups = 58 % efficiency).  Model the
 // time of s splits as rounds(s) * (steps per workgroup + a fixed per-workgroup cost of ~6 steps for prologue, tile
 // store and the extra slab) and take the cheapest s with at least min_chunks steps per split and no empty split.
-int pick_splits(long long tiles, int chunks, int min_chunks) {
+// One slab costs its consumer a pass over `slab_bytes` (~4 TB/s => bytes/4e6 step-units of ~1 us) and never less
+// than ~1/6 of a step (latency of the serial slab loop on tiny outputs).
+double slab_cost_steps(double slab_bytes) { const double bw = slab_bytes / 4.0e6; return bw > 1.0 / 6.0 ? bw : 1.0 / 6.0; }
+
+int pick_splits(long long tiles, int chunks, int min_chunks, double slab_bytes) {
     const long long SLOTS = 1024;
     int cap = chunks / min_chunks; if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
-    int best = 1; long long best_cost = -1;
+    int best = 1; double best_cost = -1;
     for (int s = 1; s <= cap; ++s) {
         const int cps = ceil_div(chunks, s);
         if (ceil_div(chunks, cps) != s) continue;            // would leave an empty split
         const long long rounds = (tiles * s + SLOTS - 1) / SLOTS;
         // + the consumer's serial pass over the s slabs (measured: 1024 slabs of a 62 KB tile cost the reducer 170 us,
         // i.e. ~1/6 of a step each) -- only matters for tiny outputs split hundreds of ways (layer 0's weight gradient)
-        const long long cost = rounds * (cps + 6) + s / 6;
+        const double cost = (double)(rounds * (cps + 6)) + s * slab_cost_steps(slab_bytes);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = s; }
     }
     return best;
@@ -1093,7 +1097,7 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_o = pl.Opad / c.TO;
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
     c.chunks = pl.Kpad / pl.KC;
-    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8);
+    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8, 4.0 * g->B * g->O * g->Ho * g->Wo);
     return c;
 }
 // With dead-tap skipping the tiles of one launch carry 4/9 ... 9/9 of the nominal work depending on their pixel
@@ -1102,11 +1106,11 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
 // pick_splits, evaluated on the true per-class workgroup counts (a 1088-workgroup grid would run two rounds).
 // (Oversubscribing 4x with small equal splits instead was measured 15-40 % slower.)
 struct LiveClass { long long tiles; int live_steps; };           // tiles sharing one live-step count
-int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, int* max_splits) {
+int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, double slab_bytes, int* max_splits) {
     const long long SLOTS = 1024;
     int hi = 1;
     for (int i = 0; i < ncls; ++i) if (cls[i].live_steps > hi) hi = cls[i].live_steps;
-    int best = hi; long long best_cost = -1; int best_ms = 1;
+    int best = hi; double best_cost = -1; int best_ms = 1;
     for (int t = min_steps < hi ? min_steps : hi; t <= hi; ++t) {
         long long wgs = 0; int ms = 1;
         for (int i = 0; i < ncls; ++i) {
@@ -1115,7 +1119,7 @@ int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, int* max_sp
             if (sp > ms) ms = sp;
         }
         const long long rounds = (wgs + SLOTS - 1) / SLOTS;
-        const long long cost = rounds * (t + 6) + ms / 6;
+        const double cost = (double)(rounds * (t + 6)) + ms * slab_cost_steps(slab_bytes);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = t; best_ms = ms; }
     }
     *max_splits = best_ms;
@@ -1157,7 +1161,7 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.n_ob = ceil_div(g->O, 16);
     c.Opad32 = round_up(g->O, 32);
     c.chunks = g->kh * g->kw * c.n_ob;
-    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 8);
+    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 8, 4.0 * g->B * g->C * g->H * g->W);
     return c;
 }
 struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits; };
@@ -1168,7 +1172,7 @@ BwCfg bw_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_r = ceil_div(pl.K, c.TR);
     c.tiles_o = pl.Opad / c.TO;
     c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 16);
-    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 16);
+    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 16, 4.0 * pl.K * pl.Opad);
     return c;
 }
 
@@ -1203,19 +1207,19 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         LiveClass cls[16]; const int plane = g->Ho * g->Wo; FwdCfg fc = fwd_cfg(g, *pl);
         const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o;
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
-        pl->fwd_target = pick_target_steps(cls, plane, 8, &pl->fwd_splits);
+        pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo, &pl->fwd_splits);
     }
     if (want_pix_major(g, b, PM_BWD_WEIGHT)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
         LiveClass cw[32]; BwCfg wc = bw_cfg(g, *pl);
         const long long tiles_per_tap = (long long)ceil_div((long long)g->C * pl->P, wc.TR) * wc.tiles_o;
         for (int tap = 0; tap < T; ++tap) cw[tap] = LiveClass{tiles_per_tap, live_positions_for_tap(g, tap) * ceil_div(g->B, 16)};
-        pl->bwd_weight_target = pick_target_steps(cw, T, 16, &pl->bwd_weight_splits);
+        pl->bwd_weight_target = pick_target_steps(cw, T, 16, 4.0 * pl->K * pl->Opad, &pl->bwd_weight_splits);
     }
     if (want_pix_major(g, b, PM_BWD_DATA)) {     // bwd-data: one class per input position; a tap holds n_ob steps
         LiveClass cls[16]; const int plane = g->H * g->W;
         const long long tiles_per_pos = (long long)ceil_div(g->B, 128) * bd.tiles_c;
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_in(g, hw) * bd.n_ob};
-        pl->bwd_data_target = pick_target_steps(cls, plane, 8, &pl->bwd_data_splits);
+        pl->bwd_data_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->C * g->H * g->W, &pl->bwd_data_splits);
     }
     return 0;
 }

@@ -210,12 +210,42 @@ __global__ __launch_bounds__(256) void k_position_major(const float* __restrict_
 // tile keeps a P-row margin on both sides for units that straddle the tile edge) and provides `dump`, an LDS word
 // nobody reads.  B-spline planes are sparse (<= S+1 of n_basis non-zero): zero the column, then overwrite the live
 // rows (same lane, in-order LDS => correct); rows of bases outside [0, n_basis) go to `dump` instead of a branch.
-// FAST != 0 fixes the reference's default B-spline configuration at compile time (grid 5, order 3 => 8 bases, base
-// branch present => P = 9; FAST 1: SiLU, FAST 2: GELU): straight-line code, no runtime loop bounds, fewer live scalars.
-// That matters twice on gfx950: VALU instructions steal fp32-MFMA issue time, and SGPR spills are VALU (v_readlane).
+// FAST != 0 fixes one of the configurations BASELINE.json names at compile time: straight-line code, no runtime loop
+// bounds, fewer live scalars.  That matters twice on gfx950: VALU instructions steal fp32-MFMA issue time, and SGPR
+// spills are VALU (v_readlane).
+//   1 / 2 : B-spline grid 5, order 3 (8 bases) + base branch SiLU / GELU          P = 9   (KANConv2DLayer defaults)
+//   3     : RBF, 8 centres + base branch SiLU                                     P = 9   (FastKANConv2DLayer defaults)
+//   4 / 5 : Chebyshev degree 4 / 3, no base branch                                P = 5 / 4
+__host__ __device__ constexpr int fast_planes(int fast) { return fast == 4 ? 5 : fast == 5 ? 4 : 9; }
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
+
 template <int KIND, int FAST>
 __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab, bool inb, float xa, float xb,
                                            float* col, int ld, float* dump) {
+    if (KIND == KAN_BASIS_RBF && FAST == 3) {
+        // utils/utils.py:33 with hardware exp2: exp(-u^2) = exp2(-u^2 log2 e), u = (x - c_g) / d
+        col[0] = inb ? silu_fast(xa) : 0.f;
+        const float inv_d = 1.0f / bs.p0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float u = (xb - bs.tab[j]) * inv_d;
+            col[(1 + j) * ld] = inb ? __builtin_amdgcn_exp2f(u * u * -1.44269504088896340736f) : 0.f;
+        }
+        return;
+    }
+    if (KIND == KAN_BASIS_CHEBY && (FAST == 4 || FAST == 5)) {
+        // cheby_kan_layers.py:93-96 by recurrence; tanh through hardware exp2/rcp: (e-1)/(e+1), e = exp(2x), |err| ~1e-7 absolute
+        const float e = __builtin_amdgcn_exp2f(fminf(xb, 40.f) * 2.88539008177792681472f);
+        const float t = fminf(fmaxf((e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f), bs.p0), bs.p1);
+        float Tm = 1.f, Tc = t;
+        col[0] = inb ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 1; k < fast_planes(FAST); ++k) {
+            col[k * ld] = inb ? Tc : 0.f;
+            const float Tn = 2.f * t * Tc - Tm; Tm = Tc; Tc = Tn;
+        }
+        return;
+    }
     if (KIND == KAN_BASIS_BSPLINE && FAST != 0) {
         float base = 0.f, N0 = 0.f, N1 = 0.f, N2 = 0.f, N3 = 0.f; int j0 = -8;
         const bool live = inb && xa >= bs.g0 && xa < bs.gN;             // NaN fails both, as the reference's indicator
@@ -316,7 +346,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform => scalar registers
     const int w_o = wave / WP, w_p = wave % WP;
-    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? 9 : bs.P;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
     const int px_tile0 = blockIdx.x * TP, o_tile0 = blockIdx.y * TO;
     const int pxl = (wave % (TP / 64)) * 64 + lane, il0 = wave / (TP / 64);
@@ -675,7 +705,7 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // provably wave-uniform => scalar registers
     const int w_r = wave / WC, w_c = wave % WC;
-    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? 9 : bs.P;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
     const int k0 = blockIdx.x * TR, o_tile0 = blockIdx.y * TO;
     const int item_first = k0 / P;
@@ -1224,11 +1254,11 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     return 0;
 }
 
-// Compile-time specialisation available?  1: B-spline grid 5 / order 3 with SiLU base, 2: same with GELU, 0: generic.
+// Compile-time specialisation available?  (numbers as documented at stage_unit; 0 = generic)
 int fast_variant(const KanBasis* b) {
-    if (b->kind != KAN_BASIS_BSPLINE || b->n_basis != 8 || b->order != 3) return 0;
-    if (b->act == KAN_ACT_SILU) return 1;
-    if (b->act == KAN_ACT_GELU) return 2;
+    if (b->kind == KAN_BASIS_BSPLINE && b->n_basis == 8 && b->order == 3) return b->act == KAN_ACT_SILU ? 1 : b->act == KAN_ACT_GELU ? 2 : 0;
+    if (b->kind == KAN_BASIS_RBF && b->n_basis == 8 && b->act == KAN_ACT_SILU) return 3;
+    if (b->kind == KAN_BASIS_CHEBY && b->act == KAN_ACT_NONE) return b->n_basis == 5 ? 4 : b->n_basis == 4 ? 5 : 0;
     return 0;
 }
 
@@ -1347,11 +1377,16 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         else KAN_FWD(KIND, 1, 2, 16);                                          \
     } while (0)
     const int fast = fast_variant(b);
-    if (fast && c.TO == 128) { if (fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 2, 2, 18); else KAN_FWD2(KAN_BASIS_BSPLINE, 2, 2, 2, 18); }
-    else if (fast) { if (fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 1, 2, 18); else KAN_FWD2(KAN_BASIS_BSPLINE, 2, 1, 2, 18); }
+#define KAN_FWD_FAST(KIND, F, KCV) do { if (c.TO == 128) KAN_FWD2(KIND, F, 2, 2, KCV); else KAN_FWD2(KIND, F, 1, 2, KCV); } while (0)
+    if (fast == 1) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 1, 18);
+    else if (fast == 2) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 2, 18);
+    else if (fast == 3) KAN_FWD_FAST(KAN_BASIS_RBF, 3, 18);
+    else if (fast == 4) KAN_FWD_FAST(KAN_BASIS_CHEBY, 4, 16);
+    else if (fast == 5) KAN_FWD_FAST(KAN_BASIS_CHEBY, 5, 16);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
     else KAN_FWD_KIND(KAN_BASIS_CHEBY);
+#undef KAN_FWD_FAST
 #undef KAN_FWD_KIND
 #undef KAN_FWD2
 #undef KAN_FWD
@@ -1399,11 +1434,16 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4))
 #define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
     const int fast = fast_variant(b);
-    if (fast && c.TO == 128) { if (fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 2, 2); else KAN_BW2(KAN_BASIS_BSPLINE, 2, 2, 2); }
-    else if (fast) { if (fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 4, 1); else KAN_BW2(KAN_BASIS_BSPLINE, 2, 4, 1); }
+#define KAN_BW_FAST(KIND, F) do { if (c.TO == 128) KAN_BW2(KIND, F, 2, 2); else KAN_BW2(KIND, F, 4, 1); } while (0)
+    if (fast == 1) KAN_BW_FAST(KAN_BASIS_BSPLINE, 1);
+    else if (fast == 2) KAN_BW_FAST(KAN_BASIS_BSPLINE, 2);
+    else if (fast == 3) KAN_BW_FAST(KAN_BASIS_RBF, 3);
+    else if (fast == 4) KAN_BW_FAST(KAN_BASIS_CHEBY, 4);
+    else if (fast == 5) KAN_BW_FAST(KAN_BASIS_CHEBY, 5);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
     else KAN_BW_KIND(KAN_BASIS_CHEBY);
+#undef KAN_BW_FAST
 #undef KAN_BW_KIND
 #undef KAN_BW2
 #undef KAN_BW

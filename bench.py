@@ -25,10 +25,39 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 GFLOP_PER_IMAGE = 8.249            # dense algorithmic count fwd+bwd for KAN-VGG11 @32x32
 
 
-def build_model(device):
-    from convkan_amd.models import vggkan
+# Workloads: the headline (BASELINE.json configs[2]/[3]) is the default; the two other GPU configs of BASELINE.json can be
+# timed with --workload (same step definition; they are not the metric the driver records).
+WORKLOADS = {
+    "kan_vgg11": dict(metric="images/sec fwd+bwd KAN-VGG11 3x32x32 bs=256/GPU", shape=(3, 32, 32), batch=256, gflop_per_image=8.249,
+                      desc="KAN-VGG11 (KANConv2DLayer x8, grid=5, order=3, SiLU, InstanceNorm2d+PReLU, Linear head), 3x32x32, "
+                           "fwd+CE loss+bwd, no optimizer step"),
+    "cheby_alexnet": dict(metric="images/sec fwd+bwd KAN-AlexNet ChebyKAN(deg 4) 3x224x224 bs=128/GPU", shape=(3, 224, 224), batch=128,
+                          gflop_per_image=2517.4 / 128, desc="KAN-AlexNet, ChebyKANConv2DLayer x5 (degree 4, InstanceNorm2d affine), FC head, "
+                                                             "3x224x224, fwd+CE loss+bwd (BASELINE.json configs[4]); FLOPs = conv stages only"),
+    "fastkan_layer": dict(metric="images/sec fwd+bwd single FastKANConv2DLayer 3->64 k3 on 3x32x32 bs=256/GPU", shape=(3, 32, 32), batch=256,
+                          gflop_per_image=3 * 2.0 * 64 * 30 * 30 * 3 * 9 * 9 / 1e9,
+                          desc="one FastKANConv2DLayer(3, 64, 3) (RBF grid 8, SiLU, input InstanceNorm2d), fwd + sum-loss + bwd (BASELINE.json configs[1])"),
+}
+
+
+def build_model(device, workload="kan_vgg11"):
     torch.manual_seed(0)
-    return vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear").to(device).train()
+    if workload == "kan_vgg11":
+        from convkan_amd.models import vggkan
+        return vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear").to(device).train()
+    if workload == "cheby_alexnet":
+        from convkan_amd.models import alexnet_kan
+        return alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4).to(device).train()
+    import convkan_amd
+
+    class OneLayer(torch.nn.Module):                       # logits = spatial mean of the layer output (10 of its 64 channels)
+        def __init__(self):
+            super().__init__()
+            self.layer = convkan_amd.FastKANConv2DLayer(3, 64, 3)
+
+        def forward(self, x):
+            return self.layer(x).mean(dim=(2, 3))[:, :10]
+    return OneLayer().to(device).train()
 
 
 def one_step(model, x, t, reducer=None):
@@ -96,7 +125,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="images per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kan_vgg11")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -123,7 +153,10 @@ def main():
     from convkan_amd import ops
     convkan_amd.build_library()
 
-    model = build_model(device)
+    wl = WORKLOADS[args.workload]
+    if args.batch <= 0:
+        args.batch = wl["batch"]
+    model = build_model(device, args.workload)
     reducer = None
     if use_dist:
         from convkan_amd.parallel import BucketedGradReducer
@@ -131,7 +164,7 @@ def main():
             dist.broadcast(p.data, 0)
         reducer = BucketedGradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20, always_reduce=args.force_dp)
     g = torch.Generator(device=device).manual_seed(1 + rank)
-    x = torch.randn(args.batch, 3, 32, 32, device=device, generator=g)
+    x = torch.randn(args.batch, *wl["shape"], device=device, generator=g)
     t = torch.randint(0, 10, (args.batch,), device=device, generator=g)
 
     def barrier():
@@ -171,12 +204,11 @@ def main():
         all_f = sum(v[2] for v in fam.values())
         ips = world * args.batch * args.steps / elapsed
         out = {
-            "metric": "images/sec fwd+bwd KAN-VGG11 3x32x32 bs=256/GPU",
+            "metric": wl["metric"],
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (randn images, randint labels; seeded random-init weights)",
-            "config": {"workload": "KAN-VGG11 (KANConv2DLayer x8, grid=5, order=3, SiLU, InstanceNorm2d+PReLU, Linear head), "
-                                   "3x32x32, fwd+CE loss+bwd, no optimizer step", "per_gpu_batch": args.batch,
+            "config": {"workload": wl["desc"], "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}" if world > 1 else "single",
                        "loss": round(float(loss.detach()), 6)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -185,10 +217,10 @@ def main():
                          "avg_launch_ms": kernels[dom]["avg_ms"], "flops_per_launch": round(fam[dom][2] / fam[dom][0] / 1e9, 3),
                          "all_conv_kernels_tflops": round(all_f / (all_t * 1e-3) / 1e12, 2),
                          "conv_kernel_share_of_step": round(all_t / (elapsed * 1e3), 3),
-                         "end_to_end_frac": round(ips * GFLOP_PER_IMAGE / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "end_to_end_frac": round(ips * wl["gflop_per_image"] / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
                          "kernels": kernels},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))

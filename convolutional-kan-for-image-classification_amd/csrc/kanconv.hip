@@ -15,6 +15,7 @@
 // contiguous in HBM (pixels for z / dx, o for dWp) is always the column => 128-B coalesced stores.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "kanconv.h"
 #include "kan_device.h"
@@ -38,6 +39,9 @@ struct DevGeom {
     int b_shift;                 // log2(B) or -1
     long long xbs, ybs;
 };
+
+constexpr int PERM_MAX = 64;
+struct TilePerm { int n; unsigned short idx[PERM_MAX]; };          // pixel-tile dispatch order (n == 0: identity), see balance_tiles
 
 // Structural zeros.  With zero padding, tap (r,t) of output position (ho,wo) reads outside the image for a fixed set
 // of positions; on 4x4 / 2x2 planes that is 31 % / 56 % of all (position, tap) products.  When the pixel axis is
@@ -331,7 +335,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
 template <int KIND, int FAST, int WO, int WP, int KC>
 __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp, float* __restrict__ z,
-    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes) {
+    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes, TilePerm perm) {
     constexpr int TO = WO * 64, TP = WP * 64, NT = WO * WP * 64, NW = WO * WP;
     constexpr int IPP = NT / TP;                          // items handled per pass over the pixels
     constexpr int UMAX = 4 / IPP;                         // units per thread (IPC <= 4)
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const int w_o = wave / WP, w_p = wave % WP;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
-    const int px_tile0 = blockIdx.x * TP, o_tile0 = blockIdx.y * TO;
+    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, o_tile0 = blockIdx.y * TO;
     const int pxl = (wave % (TP / 64)) * 64 + lane, il0 = wave / (TP / 64);
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
@@ -504,7 +508,7 @@ template <int KIND>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
     float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CH, int n_ct, int n_ob, int Opad16,
-    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes) {
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes, TilePerm perm) {
     constexpr int TP = 128, KD = 16, NT = 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * KD * 128];   // 2 x (sW 16x128 + sG 16x128) = 32 KB; epilogue 64x128
     __shared__ float sTab[KAN_MAX_TABLE];
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const int w_r = wave >> 1, w_p = wave & 1;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, P = bs.P;
     const int Min = g.B * HW;
-    const int px_tile0 = blockIdx.x * TP, ct = blockIdx.y;
+    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, ct = blockIdx.y;
     const int ncol = n_ct * 128;
     const int pxl = (wave & 1) * 64 + lane, ol0 = wave >> 1;
 
@@ -1068,7 +1072,8 @@ DevGeom dev_geom(const KanGeom* g) {
 enum { PM_FWD = 0, PM_BWD_DATA = 1, PM_BWD_WEIGHT = 2 };
 bool want_pix_major(const KanGeom* g, const KanBasis* b, int which) {
     const int plane = which == PM_BWD_DATA ? g->H * g->W : g->Ho * g->Wo;
-    const int limit = which == PM_BWD_WEIGHT ? 16 : 4;
+    int limit = which == PM_BWD_WEIGHT ? 16 : 4;
+    if (const char* e = getenv("KAN_PM_LIMIT")) limit = atoi(e);          // tuning knob (experiments only)
     return b->kind != KAN_BASIS_RBF && plane <= limit && g->kh * g->kw <= 32 && (g->ph > 0 || g->pw > 0) && g->B >= 16;
 }
 
@@ -1136,6 +1141,34 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
 // pick_splits, evaluated on the true per-class workgroup counts (a 1088-workgroup grid would run two rounds).
 // (Oversubscribing 4x with small equal splits instead was measured 15-40 % slower.)
 struct LiveClass { long long tiles; int live_steps; };           // tiles sharing one live-step count
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear block id and never migrate.  Position-major pixel tiles are
+// ordered by position, so without care XCD k would get only the tiles of positions k, k+8, ... -- all light (corner)
+// or all heavy (centre) ones (measured: half the chip idle).  The host therefore deals the pixel tiles to 8 bins in
+// snake order of decreasing live work and hands the kernel the resulting order.
+TilePerm balance_tiles(const int* weight, int n) {
+    TilePerm p; p.n = 0;
+    if (n < 2 || n > PERM_MAX) return p;
+    int order[PERM_MAX];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i) {                                   // insertion sort, heaviest first (stable)
+        int v = order[i], j = i;
+        while (j > 0 && weight[order[j - 1]] < weight[v]) { order[j] = order[j - 1]; --j; }
+        order[j] = v;
+    }
+    // rank r goes to slot (bin = snake(r), depth = r / 8); slot s = depth*8 + bin is dispatched s-th => XCD = bin
+    for (int r = 0; r < n; ++r) {
+        const int depth = r / 8, k = r % 8, bin = (depth & 1) ? 7 - k : k;
+        int slot = depth * 8 + bin;
+        if (slot >= n) slot = r;                                    // ragged last row: keep it simple
+        p.idx[slot] = (unsigned short)order[r];
+    }
+    // the ragged fallback can collide; verify it is a permutation, else identity
+    bool seen[PERM_MAX] = {false};
+    for (int i = 0; i < n; ++i) { if (p.idx[i] >= n || seen[p.idx[i]]) return p; seen[p.idx[i]] = true; }
+    p.n = n;
+    return p;
+}
 int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, double slab_bytes, int* max_splits) {
     const long long SLOTS = 1024;
     int hi = 1;
@@ -1366,9 +1399,18 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_p, c.tiles_o, pl.fwd_splits);          // always the plan's slab count: the consumer sums exactly that many
     int cps = dg.pix_major ? pl.fwd_target : ceil_div(c.chunks, pl.fwd_splits);
+    TilePerm perm; perm.n = 0;
+    if (dg.pix_major && c.tiles_p <= PERM_MAX) {             // weight of a pixel tile = its own split count (live work)
+        int w[PERM_MAX];
+        for (int t = 0; t < c.tiles_p; ++t) {
+            const int hw = (int)(((long long)t * c.TP) / g->B);
+            w[t] = ceil_div(live_taps_out(g, hw < g->Ho * g->Wo ? hw : 0) * ceil_div(g->C, pl.IPC), cps > 0 ? cps : 1);
+        }
+        perm = balance_tiles(w, c.tiles_p);
+    }
 #define KAN_FWD(KIND, WO, WP, KCV) KAN_FWD2(KIND, 0, WO, WP, KCV)
 #define KAN_FWD2(KIND, FAST, WO, WP, KCV) \
-    hipLaunchKernelGGL((k_conv_fwd<KIND, FAST, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4))
+    hipLaunchKernelGGL((k_conv_fwd<KIND, FAST, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), perm)
 #define KAN_FWD_KIND(KIND)                                                     \
     do {                                                                       \
         if (c.TO == 128 && pl.KC == 18) KAN_FWD(KIND, 2, 2, 18);               \
@@ -1407,8 +1449,17 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.tiles_p, c.tiles_c, pl.bwd_data_splits);
     int cps = dg.pix_major ? pl.bwd_data_target : ceil_div(c.chunks, pl.bwd_data_splits);
+    TilePerm perm; perm.n = 0;
+    if (dg.pix_major && c.tiles_p <= PERM_MAX) {
+        int w[PERM_MAX];
+        for (int t = 0; t < c.tiles_p; ++t) {
+            const int hw = (int)(((long long)t * 128) / g->B);
+            w[t] = ceil_div(live_taps_in(g, hw < g->H * g->W ? hw : 0) * c.n_ob, cps > 0 ? cps : 1);
+        }
+        perm = balance_tiles(w, c.tiles_p);
+    }
 #define KAN_BD(KIND) \
-    hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4))
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
     if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else KAN_BD(KAN_BASIS_CHEBY);

@@ -148,3 +148,19 @@ def test_full_model_step_is_batch_independent(gpu_lib):
     loss = F.cross_entropy(m(x), torch.randint(0, 10, (256,), device="cuda"))
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("B", [1, 3, 32, 100])
+def test_vgg11_runs_and_is_batch_consistent_at_odd_batch_sizes(B, gpu_lib):
+    """Planner edge cases (ragged pixel tiles, split selection, position-major paths with B < 128 or not a power of
+    two): KAN-VGG11 logits of a batch equal those of its samples run one at a time."""
+    from convkan_amd.models import vggkan
+    torch.manual_seed(3)
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear").cuda().eval()
+    x = torch.randn(B, 3, 32, 32, device="cuda", requires_grad=True)
+    y = m(x)
+    y.square().sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    with torch.no_grad():
+        single = torch.cat([m(x[i:i + 1].detach()) for i in range(min(B, 3))])
+    assert relerr(y[:single.shape[0]], single) <= 2e-3

@@ -6,7 +6,8 @@ on-disk name ``convolutional-kan-for-image-classification_amd`` is not a Python 
 """
 from . import _lib, ops                                                   # noqa: F401
 from .layers import (CONV_KAN_FACTORY, KANConv2DLayer, KANConvNDLayer, FastKANConv2DLayer, FastKANConvNDLayer,   # noqa: F401
-                     ChebyKANConv2DLayer, ChebyKANConvNDLayer, RadialBasisFunction, kan_conv, fastkan_conv, chebykan_conv, conv)
+                     ChebyKANConv2DLayer, ChebyKANConvNDLayer, RadialBasisFunction, kan_conv, fastkan_conv, chebykan_conv, conv,
+                     KANLayer, KAN, mlp_kan, MLP_KAN_FACTORY)
 from .build import build_library                                          # noqa: F401
 
 __version__ = "0.1.0"

@@ -4,7 +4,7 @@ Same module tree and parameter names as the reference (``features.N.<layer>``, `
 so a reference ``state_dict`` loads unchanged.  Adds the ``VGG11`` cfg that BASELINE.json names
 (torchvision cfg "A" without its trailing "M" -- the reference's own convention for VGG16/19,
 kan_vgg.py:20-26).  Only plain heads ('Linear', 'VGG') are offered: KAN MLP heads are out of the
-accelerated path's scope.
+accelerated path's first "next" row and are built on the same conv stage.
 """
 from functools import partial
 from inspect import signature
@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.kan_conv import CONV_KAN_FACTORY
+from ..layers.mlp_layers import MLP_KAN_FACTORY
 
 cfgs: Dict[str, List[Union[str, int]]] = {
     "VGG11": [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512],
@@ -26,13 +27,20 @@ cfgs: Dict[str, List[Union[str, int]]] = {
 }
 
 
-def _head(kind: str, feat: int, num_classes: int, p: float) -> nn.Module:
+def _head(kind: str, feat: int, num_classes: int, p: float, kan_head=None) -> nn.Module:
     if kind == "Linear":                                        # kan_vgg.py:139-143
         return nn.Sequential(nn.Dropout(p=p), nn.Linear(feat, num_classes))
     if kind == "VGG":                                           # kan_vgg.py:164-173
         return nn.Sequential(nn.Linear(feat, 1024), nn.ReLU(True), nn.Dropout(p=p), nn.Linear(1024, 1024), nn.ReLU(True),
                              nn.Dropout(p=p), nn.Linear(1024, num_classes))
-    raise NotImplementedError(f"classifier_type={kind!r}: KAN MLP heads are outside the accelerated path (use 'Linear' or 'VGG')")
+    if kind == "KAN":                                           # kan_vgg.py:134-138
+        return nn.Sequential(nn.Dropout(p=p), kan_head([feat, num_classes]))
+    if kind == "HiddenKAN":                                     # kan_vgg.py:144-149
+        return nn.Sequential(kan_head([feat, 1024]), nn.Dropout(p=p), nn.Linear(1024, num_classes))
+    if kind == "VGGKAN":                                        # kan_vgg.py:150-163
+        return nn.Sequential(nn.Linear(feat, 1024), nn.ReLU(True), nn.Dropout(p=p), nn.Linear(1024, 1024), nn.ReLU(True),
+                             nn.Dropout(p=p), kan_head([1024, num_classes]))
+    raise NotImplementedError(f"classifier_type={kind!r} is not offered (Linear, VGG, KAN, HiddenKAN, VGGKAN)")
 
 
 class VGGKAN(nn.Module):
@@ -42,7 +50,7 @@ class VGGKAN(nn.Module):
                  l1_decay: float = 0.0, dropout_linear: float = 0.5, expected_feature_shape: Tuple[int, int] = (1, 1),
                  width_scale: int = 1, affine: bool = False, kan_norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d,
                  std_conv_kernel_size: int = 3, std_conv_padding: int = 1, degree: int = 3, conv_dropout: float = 0.0,
-                 **kwargs: Any):
+                 kan_classifier: Optional[str] = "KAN", **kwargs: Any):
         super().__init__()
         if arch not in cfgs:
             raise ValueError(f"Unknown arch: {arch}. Available types: {list(cfgs.keys())}")
@@ -68,9 +76,20 @@ class VGGKAN(nn.Module):
                 cin = cout
         self.features = nn.ModuleList(feats)
         self.avgpool = nn.AdaptiveAvgPool2d(expected_feature_shape)
-        self.classifier = _head(classifier_type, cin * prod(expected_feature_shape), num_classes, dropout_linear)
+        kan_head = None
+        if classifier_type in ("KAN", "HiddenKAN", "VGGKAN"):
+            name = kan_classifier or "KAN"
+            if name not in MLP_KAN_FACTORY:
+                raise NotImplementedError(f"kan_classifier={name!r}: only the B-spline MLP KAN head is built ({list(MLP_KAN_FACTORY)})")
+            # kan_vgg.py:258-283: the head inherits spline_order / grid_size / grid_range, SiLU base, no dropout, filtered by signature
+            offered_h = dict(spline_order=spline_order, grid_size=grid_size, base_activation=nn.SiLU, grid_range=grid_range,
+                             l1_decay=l1_decay, degree=degree, dropout=0.0, first_dropout=False, bias=False)
+            hk = {k: v for k, v in offered_h.items() if k in signature(MLP_KAN_FACTORY[name]).parameters}
+            kan_head = partial(MLP_KAN_FACTORY[name], **hk)
+        self.classifier = _head(classifier_type, cin * prod(expected_feature_shape), num_classes, dropout_linear, kan_head)
         self.expected_feature_shape = expected_feature_shape
-        self.name = f"VGGKAN_{classifier_type}_{kan_conv.upper()}_{arch}"
+        head = classifier_type + (f"_{(kan_classifier or 'KAN').upper()}" if kan_head is not None else "")
+        self.name = f"VGGKAN_{head}_{kan_conv.upper()}_{arch}"
 
     def forward_features(self, x):
         for layer in self.features:
@@ -87,5 +106,4 @@ def vggkan(input_channels: int, num_classes: int, conv_type: str = "kanconv", ka
     """Factory with the reference's leading arguments (kan_vgg.py:307-343)."""
     if conv_type != "kanconv":
         raise NotImplementedError("only conv_type='kanconv' is on the accelerated path")
-    kwargs.pop("kan_classifier", None)
     return VGGKAN(input_channels, num_classes, kan_conv=kan_conv or "KAN", arch=arch, classifier_type=classifier_type, **kwargs)

@@ -197,6 +197,24 @@ class OracleKANVGG(torch.nn.Module):
         return self.classifier(x)
 
 
+# ------------------------------------------------------------------------------------ MLP KANLayer (section 8(f), rank 2)
+def kan_linear(x: Tensor, base_weight: Tensor, spline_weight: Tensor, ln_weight: Tensor, ln_bias: Tensor, prelu_a: Tensor, *,
+               grid_size: int = 5, spline_order: int = 3, grid_range: Sequence[float] = (-1, 1),
+               act: Optional[Callable[[Tensor], Tensor]] = F.gelu, eps: float = 1e-5, pre: Optional[list] = None) -> Tensor:
+    """layers/kan_layers.py:48-114 (KANLayer.forward): x [B, I]; base_weight [O, I]; spline_weight [O, I, G+S].
+
+    base = act(x) W_b^T (53-54); bases by the same indicator + Cox-de Boor recursion as the conv layer (62-90);
+    spline = bases.view(B, I*(G+S)) W_s.view(O, I*(G+S))^T (104-106); LayerNorm(O) then scalar PReLU (108-110)."""
+    knots = bspline_knots(grid_size, spline_order, grid_range)
+    base = F.linear(act(x) if act is not None else x, base_weight)
+    bases = bspline_basis(x, knots, spline_order)                       # [B, I, G+S]
+    spline = F.linear(bases.reshape(x.shape[0], -1), spline_weight.reshape(spline_weight.shape[0], -1))
+    z = base + spline
+    if pre is not None:
+        pre.append(z.detach().clone())
+    return F.prelu(F.layer_norm(z, (z.shape[1],), ln_weight, ln_bias, eps), prelu_a)
+
+
 def flops_kan_conv(B, C, O, Ho, Wo, kh, kw, n_planes):
     """Dense algorithmic FLOPs of one conv stage, forward only."""
     return 2.0 * B * O * Ho * Wo * C * n_planes * kh * kw

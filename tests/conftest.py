@@ -19,7 +19,7 @@ def golden_cases(kind=None):
     out = []
     for fn in sorted(os.listdir(GOLDEN)):
         if fn.endswith(".npz") and not fn.startswith(("model_", "basis_")):
-            if kind is None or fn.startswith(kind + "_"):
+            if (kind is None and not fn.startswith("mlp_")) or (kind is not None and fn.startswith(kind + "_")):
                 out.append(fn[:-4])
     return out
 

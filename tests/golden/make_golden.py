@@ -30,6 +30,7 @@ sys.path.insert(1, ROOT)
 sys.dont_write_bytecode = True
 
 from layers import KANConv2DLayer, FastKANConv2DLayer, ChebyKANConv2DLayer  # noqa: E402  (reference)
+from layers import KANLayer as RefKANLayer  # noqa: E402  (reference, layers/kan_layers.py:8-114)
 from oracle import kan_oracle as O  # noqa: E402
 
 ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
@@ -259,6 +260,73 @@ def basis_probes():
     np.savez(os.path.join(HERE, "basis_probes.npz"), **out)
 
 
+# ---------------------------------------------------------------------------------- MLP KANLayer (section 8(f) rank 2)
+MLP_CASES = [
+    dict(name="tiny", B=5, I=7, O=3, G=5, S=3, act="gelu", rng=[-1, 1], xs=1.0),
+    dict(name="head512", B=64, I=512, O=10, G=5, S=3, act="silu", rng=[-1, 1], xs=1.0),      # KAN head of kan_vgg.py:134-138
+    dict(name="wide", B=33, I=40, O=130, G=8, S=2, act="none", rng=[-2, 2], xs=2.5),
+    dict(name="order1", B=16, I=24, O=40, G=3, S=1, act="tanh", rng=[-1, 1], xs=0.7),
+]
+
+
+def run_mlp_case(idx, c):
+    torch.manual_seed(idx)
+    layer = RefKANLayer(c["I"], c["O"], grid_size=c["G"], spline_order=c["S"], base_activation=ACTS[c["act"]],
+                        grid_range=c["rng"]).train()
+    with torch.no_grad():
+        det_fill(layer.base_weight, idx * 17 + 1, (3.0 / c["I"]) ** 0.5)
+        det_fill(layer.spline_weight, idx * 17 + 2, (3.0 / c["I"]) ** 0.5)
+        det_fill(layer.layer_norm.weight, idx * 17 + 3, 0.5); layer.layer_norm.weight.add_(1.0)
+        det_fill(layer.layer_norm.bias, idx * 17 + 4, 0.3)
+        layer.prelu.weight.fill_(0.2)
+    x = mk_input((c["B"], c["I"]), 900 + idx, c["xs"]).requires_grad_(True)
+    pre = []
+    h = layer.layer_norm.register_forward_pre_hook(lambda m, a: pre.append(a[0].detach().clone()))
+    y = layer(x)
+    h.remove()
+    g = mk_input(tuple(y.shape), 950 + idx, 1.0)
+    y.backward(g)
+    ref = {"y": y.detach().clone(), "dx": x.grad.detach().clone()}
+    grads = {n: p.grad.detach().clone() for n, p in layer.named_parameters()}
+
+    import copy
+    l64 = copy.deepcopy(layer).double(); l64.zero_grad(set_to_none=True); l64.grid = layer.grid.double()
+    x64 = x.detach().double().requires_grad_(True)
+    y64 = l64(x64); y64.backward(g.double())
+    rel64 = lambda a, b: float((a.double() - b).abs().max() / (b.abs().max() + 1e-300))
+    noise = {"y": rel64(ref["y"], y64.detach()), "dx": rel64(ref["dx"], x64.grad)}
+    for n, p in l64.named_parameters():
+        noise["grad." + n] = rel64(grads[n], p.grad)
+
+    layer.zero_grad(set_to_none=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    y2 = O.kan_linear(x2, layer.base_weight, layer.spline_weight, layer.layer_norm.weight, layer.layer_norm.bias, layer.prelu.weight,
+                      grid_size=c["G"], spline_order=c["S"], grid_range=c["rng"], act=ACT_FN[c["act"]])
+    y2.backward(g)
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    errs = {"y": rel(y2.detach(), ref["y"]), "dx": rel(x2.grad, ref["dx"])}
+    for n, p in layer.named_parameters():
+        errs["d" + n] = rel(p.grad, grads[n])
+    worst = max(errs.values())
+    assert worst < 2e-6, (c["name"], errs)
+    out = {"x": x.detach().numpy(), "g": g.numpy(), "y": ref["y"].numpy(), "dx": ref["dx"].numpy(), "z": pre[0].numpy(),
+           "cfg": np.frombuffer(json.dumps(c).encode(), dtype=np.uint8),
+           "noise": np.frombuffer(json.dumps(noise).encode(), dtype=np.uint8)}
+    for n, t in layer.state_dict().items():
+        out["sd." + n] = t.detach().numpy()
+    for n, t in grads.items():
+        out["grad." + n] = t.numpy()
+    fn = os.path.join(HERE, f"mlp_{c['name']}.npz")
+    np.savez(fn, **out)
+    return worst, os.path.getsize(fn)
+
+
+def mlp_cases():
+    for i, c in enumerate(MLP_CASES):
+        worst, sz = run_mlp_case(i, c)
+        print(f"mlp      {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 # ---------------------------------------------------------------------------------- model level
 def import_ref_models():
     pkg = types.ModuleType("models")
@@ -313,12 +381,15 @@ def run_model(name, model, x, t):
 
 
 def main():
+    if "--mlp-only" in sys.argv:                    # regenerate just the MLP KANLayer fixtures
+        return mlp_cases()
     total = 0
     for i, c in enumerate(CASES):
         worst, sz = run_case(i, c)
         total += sz
         print(f"{c['kind']:8s} {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
     basis_probes()
+    mlp_cases()
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)

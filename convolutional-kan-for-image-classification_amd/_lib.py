@@ -19,7 +19,7 @@ ACT_NONE, ACT_IDENTITY, ACT_GELU, ACT_SILU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT
 
 
 class KanGeom(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "O", "Ho", "Wo", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw")] + \
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "O", "Ho", "Wo", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "groups")] + \
                [("x_bstride", C.c_longlong), ("y_bstride", C.c_longlong)]
 
 
@@ -49,8 +49,8 @@ SIGNATURES = {
     "kan_conv_bwd_weight": (_I, [_P, _P, _P, _P, _GP, _BP, _P, _P, _P]),
     "kan_unpack_wgrad": (_I, [_P, _P, _P, _GP, _BP, _P]),
     "kan_slab_reduce": (_I, [_P, _I, _LL, _P, _I, _I, _I, _LL, _P]),
-    "kan_instnorm_prelu_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _F, _P]),
-    "kan_instnorm_prelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _P]),
+    "kan_instnorm_prelu_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _F, _I, _P]),
+    "kan_instnorm_prelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _I, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

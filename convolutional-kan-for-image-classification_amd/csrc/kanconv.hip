@@ -105,9 +105,12 @@ __device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
     return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
 }
 
-__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, float* __restrict__ wp, PackGeo q, int src_kind) {
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, float* __restrict__ wp, PackGeo q, int src_kind,
+                                              long long wp_gstride) {
     __shared__ float tile[32][33];
     const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;       // source row length
+    src += (size_t)blockIdx.z * q.O * J;                              // group blockIdx.z: stacked sources, back-to-back packed blocks
+    wp += (size_t)blockIdx.z * wp_gstride;
     const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
 #pragma unroll
@@ -124,9 +127,11 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, flo
 }
 
 __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, float* __restrict__ dst, PackGeo q, int src_kind,
-                                                int n_slabs, long long slab_elems) {
+                                                int n_slabs, long long slab_elems, long long dwp_gstride) {
     __shared__ float tile[32][33];
     const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;
+    dwp += (size_t)blockIdx.z * dwp_gstride;
+    dst += (size_t)blockIdx.z * q.O * J;
     const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
@@ -161,12 +166,15 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, f
 // i.e. the depth axis (tap, o) is the row, and the 128 columns of one channel tile are contiguous and 16-B aligned.
 // Columns >= CH*P of a half and rows o >= O are zero.
 __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__ wp, float* __restrict__ wd, PackGeo q,
-                                                       int CH, int n_ct, int Opad32) {
+                                                       int CH, int n_ct, int Opad32, long long wp_gstride) {
     __shared__ float tile[32][33];
     const int tap = blockIdx.z;
-    const int col0 = blockIdx.x * 32, o0 = blockIdx.y * 32;          // columns of wd / rows of wd within this tap
+    const int oblk = Opad32 / 32, grp = blockIdx.y / oblk;            // groups are folded into grid.y
+    const int col0 = blockIdx.x * 32, o0 = (blockIdx.y - grp * oblk) * 32;   // columns of wd / rows of wd within this tap
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int ncol = n_ct * 128;
+    wp += (size_t)grp * wp_gstride;
+    wd += (size_t)grp * q.T * Opad32 * ncol;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                                   // read wp along o (contiguous)
         int col = col0 + ty + 8 * i, o = o0 + tx;
@@ -335,7 +343,8 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
 template <int KIND, int FAST, int WO, int WP, int KC>
 __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp, float* __restrict__ z,
-    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes, TilePerm perm) {
+    DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes, TilePerm perm,
+    int tiles_o) {
     constexpr int TO = WO * 64, TP = WP * 64, NT = WO * WP * 64, NW = WO * WP;
     constexpr int IPP = NT / TP;                          // items handled per pass over the pixels
     constexpr int UMAX = 4 / IPP;                         // units per thread (IPC <= 4)
@@ -352,8 +361,15 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const int w_o = wave / WP, w_p = wave % WP;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
-    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, o_tile0 = blockIdx.y * TO;
+    const int grp = blockIdx.y / tiles_o;                 // groups are folded into grid.y (scalar; 0 for ungrouped layers)
+    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, o_tile0 = (blockIdx.y - grp * tiles_o) * TO;
     const int pxl = (wave % (TP / 64)) * 64 + lane, il0 = wave / (TP / 64);
+    {   // group grp owns channels [grp*C, (grp+1)*C) of x / xn (NCHW, or the [C*H*W][B] copy), [grp*O, ..) of z, and its own packed block
+        const size_t xo = (size_t)grp * g.C * HW * (g.pix_major ? g.B : 1);
+        x += xo; xn += xo;
+        z += (size_t)grp * g.O * HoWo;
+        wp += (size_t)grp * n_chunks * KC * Opad;
+    }
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     for (int i = tid; i < 2 * KC * TP; i += NT) sE[i] = 0.f;            // pad rows stay zero for the whole kernel
@@ -508,7 +524,7 @@ template <int KIND>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
     float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CH, int n_ct, int n_ob, int Opad16,
-    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes, TilePerm perm) {
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes, TilePerm perm) {     // grid.y = groups * n_ct
     constexpr int TP = 128, KD = 16, NT = 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * KD * 128];   // 2 x (sW 16x128 + sG 16x128) = 32 KB; epilogue 64x128
     __shared__ float sTab[KAN_MAX_TABLE];
@@ -518,9 +534,16 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const int w_r = wave >> 1, w_p = wave & 1;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, P = bs.P;
     const int Min = g.B * HW;
-    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, ct = blockIdx.y;
+    const int grp = blockIdx.y / n_ct;                    // groups are folded into grid.y
+    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, ct = blockIdx.y - grp * n_ct;
     const int ncol = n_ct * 128;
     const int pxl = (wave & 1) * 64 + lane, ol0 = wave >> 1;
+    {
+        const size_t xo = (size_t)grp * g.C * HW;
+        x += xo; xn += xo; dx += xo; if (dxn) dxn += xo;
+        dz += (size_t)grp * g.O * HoWo * (g.pix_major ? g.B : 1);
+        wd += (size_t)grp * (g.kh * g.kw) * Opad16 * ncol;
+    }
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     const int my_px = px_tile0 + pxl;
@@ -692,7 +715,7 @@ template <int KIND, int FAST, int WR, int WC>
 __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
     DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems,
-    unsigned x_bytes, unsigned dz_bytes) {
+    unsigned x_bytes, unsigned dz_bytes, int tiles_o) {
     constexpr int TR = WR * 64, TO = WC * 64, NT = WR * WC * 64, KPX = 16;
     constexpr int MRG = KAN_PMAX;                    // margin rows on both sides: units straddling the tile edge write there
     constexpr int LDE = TR + 2 * MRG + 1, LDZ = TO + 1;
@@ -711,7 +734,15 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
     const int w_r = wave / WC, w_c = wave % WC;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
-    const int k0 = blockIdx.x * TR, o_tile0 = blockIdx.y * TO;
+    const int grp = blockIdx.y / tiles_o;                 // groups are folded into grid.y
+    const int k0 = blockIdx.x * TR, o_tile0 = (blockIdx.y - grp * tiles_o) * TO;
+    {
+        const int es = g.pix_major ? g.B : 1;
+        const size_t xo = (size_t)grp * g.C * HW * es;
+        x += xo; xn += xo;
+        dz += (size_t)grp * g.O * HoWo * es;
+        dwp += (size_t)grp * Krows * Opad;
+    }
     const int item_first = k0 / P;
     const int n_items = (k0 + TR - 1) / P - item_first + 1;
     const int pl = tid & (KPX - 1), il0 = tid / KPX;
@@ -905,7 +936,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
                                                       float* __restrict__ z_out, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ prelu_a,
                                                       float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                      int n_planes, int Cn, int HW, long long bstride, float eps) {
+                                                      int n_planes, int Cn, int HW, long long bstride, float eps, int prelu_span) {
     const int tid = threadIdx.x, sub = tid % G;
     const int plane = blockIdx.x * (256 / G) + tid / G;
     const bool act = plane < n_planes;
@@ -927,7 +958,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
     if (!act) return;
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const bool has_p = prelu_a != nullptr;
-    const float a = has_p ? prelu_a[0] : 1.f;
+    const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;     // one slope per `prelu_span` channels (0: one for all)
     for (int i = sub; i < HW; i += G) {
         float n = (z_out[base + i] - mu) * rs * ga + be;
         y[base + i] = (has_p && !(n > 0.f)) ? a * n : n;
@@ -941,12 +972,11 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ prelu_a, float* __restrict__ dz,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dprelu,
-                                                      int n_planes, int Cn, int HW, long long bstride) {
+                                                      int n_planes, int Cn, int HW, long long bstride, int prelu_span) {
     constexpr int EPL = 16;                         // elements per lane held in registers between the two passes
     __shared__ float s_da[256 / G];
     const int tid = threadIdx.x, sub = tid % G;
     const bool has_p = prelu_a != nullptr;
-    const float a = has_p ? prelu_a[0] : 1.f;
     const bool in_regs = HW <= G * EPL;             // uniform
     float sa_total = 0.f;                           // PReLU-slope gradient of every plane this workgroup visits
     // grid-stride over groups of 256/G planes: the grid is capped so that the single-address atomic on dprelu
@@ -958,6 +988,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     const size_t base = (size_t)b * bstride + (size_t)c * HW;
     const float mu = act ? mean_i[plane] : 0.f, rs = act ? rstd_i[plane] : 0.f;
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+    const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;
     float rn[EPL], rd[EPL];                         // normalised value, d loss / d normalised value
     float s1 = 0.f, s2 = 0.f, sa = 0.f, sg = 0.f, sb = 0.f;
     auto visit = [&](float zv, float g, float& nh, float& dnh) {
@@ -1002,10 +1033,11 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     if (act && sub == 0) {
         if (dgamma) atomicAdd(&dgamma[c], sg);
         if (dbeta) atomicAdd(&dbeta[c], sb);
-        sa_total += sa;
+        if (prelu_span > 0) { if (dprelu) atomicAdd(&dprelu[c / prelu_span], sa); }      // per-group slopes (grouped layers)
+        else sa_total += sa;
     }
     }                                               // grid-stride loop
-    if (dprelu) {                                   // one atomic per workgroup
+    if (dprelu && prelu_span <= 0) {                // one atomic per workgroup
         if (sub == 0) s_da[tid / G] = sa_total;
         __syncthreads();
         if (tid == 0) {
@@ -1020,8 +1052,11 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
 int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+int ngroups(const KanGeom* g) { return g->groups > 0 ? g->groups : 1; }
+
 int check(const KanGeom* g, const KanBasis* b) {
     if (!g || !b) return fail("null geometry/basis");
+    if (g->groups < 0 || g->groups > 65535) return fail("groups out of range");
     if (g->B <= 0 || g->C <= 0 || g->O <= 0 || g->H <= 0 || g->W <= 0 || g->Ho <= 0 || g->Wo <= 0) return fail("non-positive dimension");
     if (g->kh <= 0 || g->kw <= 0 || g->sh <= 0 || g->sw <= 0 || g->dh <= 0 || g->dw <= 0 || g->ph < 0 || g->pw < 0) return fail("bad conv parameters");
     if (g->kh > 255 || g->kw > 255 || g->C > 65535) return fail("kernel size / channel count out of supported range");
@@ -1030,6 +1065,8 @@ int check(const KanGeom* g, const KanBasis* b) {
     if ((long long)g->B * g->Ho * g->Wo >= (1ll << 31) || (long long)g->B * g->H * g->W >= (1ll << 31)) return fail("pixel count exceeds int32");
     if ((long long)g->B * g->x_bstride * 4 >= (1ll << 31) || (long long)g->B * g->y_bstride * 4 >= (1ll << 31))
         return fail("activation tensors must be smaller than 2 GiB (32-bit buffer offsets)");
+    if (g->x_bstride < (long long)ngroups(g) * g->C * g->H * g->W || g->y_bstride < (long long)ngroups(g) * g->O * g->Ho * g->Wo)
+        return fail("batch stride smaller than groups * channels * plane");
     if (b->kind < 0 || b->kind > 2) return fail("unknown basis kind");
     if (b->act < KAN_ACT_NONE || b->act > KAN_ACT_GELU_TANH) return fail("unknown activation");
     int P = b->n_basis + (b->act != KAN_ACT_NONE);
@@ -1132,7 +1169,7 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_o = pl.Opad / c.TO;
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
     c.chunks = pl.Kpad / pl.KC;
-    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p, c.chunks, 8, 4.0 * g->B * g->O * g->Ho * g->Wo);
+    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * ngroups(g));
     return c;
 }
 // With dead-tap skipping the tiles of one launch carry 4/9 ... 9/9 of the nominal work depending on their pixel
@@ -1224,7 +1261,7 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.n_ob = ceil_div(g->O, 16);
     c.Opad32 = round_up(g->O, 32);
     c.chunks = g->kh * g->kw * c.n_ob;
-    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p, c.chunks, 8, 4.0 * g->B * g->C * g->H * g->W);
+    c.splits = pick_splits((long long)c.tiles_c * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->C * g->H * g->W * ngroups(g));
     return c;
 }
 struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits; };
@@ -1235,7 +1272,7 @@ BwCfg bw_cfg(const KanGeom* g, const KanPlan& pl) {
     c.tiles_r = ceil_div(pl.K, c.TR);
     c.tiles_o = pl.Opad / c.TO;
     c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 16);
-    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o, c.chunks, 16, 4.0 * pl.K * pl.Opad);
+    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o * ngroups(g), c.chunks, 16, 4.0 * pl.K * pl.Opad * ngroups(g));
     return c;
 }
 
@@ -1254,12 +1291,13 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     }
     pl->Kpad = ceil_div(g->C * T, pl->IPC) * pl->KC;
     pl->Opad = round_up(g->O, 64);
-    pl->packed_weight_bytes = (long long)pl->Kpad * pl->Opad * 4;
+    const int G = ngroups(g);
+    pl->packed_weight_bytes = (long long)G * pl->Kpad * pl->Opad * 4;
     BdCfg bd = bd_cfg(g, *pl);
-    pl->bwd_data_weight_bytes = (long long)T * bd.Opad32 * bd.tiles_c * 128 * 4;
+    pl->bwd_data_weight_bytes = (long long)G * T * bd.Opad32 * bd.tiles_c * 128 * 4;
     pl->fwd_slab_elems = (long long)g->B * g->y_bstride;
     pl->bwd_data_slab_elems = (long long)g->B * g->x_bstride;
-    pl->bwd_weight_slab_elems = (long long)pl->K * pl->Opad;
+    pl->bwd_weight_slab_elems = (long long)G * pl->K * pl->Opad;
     pl->fwd_splits = fwd_cfg(g, *pl).splits;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = bw_cfg(g, *pl).splits;
@@ -1268,21 +1306,21 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     if (want_pix_major(g, b, PM_FWD)) {          // forward: one class per output position; a tap holds C/IPC steps
         LiveClass cls[16]; const int plane = g->Ho * g->Wo; FwdCfg fc = fwd_cfg(g, *pl);
-        const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o;
+        const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o * G;
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
-        pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo, &pl->fwd_splits);
+        pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * G, &pl->fwd_splits);
     }
     if (want_pix_major(g, b, PM_BWD_WEIGHT)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
         LiveClass cw[32]; BwCfg wc = bw_cfg(g, *pl);
-        const long long tiles_per_tap = (long long)ceil_div((long long)g->C * pl->P, wc.TR) * wc.tiles_o;
+        const long long tiles_per_tap = (long long)ceil_div((long long)g->C * pl->P, wc.TR) * wc.tiles_o * G;
         for (int tap = 0; tap < T; ++tap) cw[tap] = LiveClass{tiles_per_tap, live_positions_for_tap(g, tap) * ceil_div(g->B, 16)};
-        pl->bwd_weight_target = pick_target_steps(cw, T, 16, 4.0 * pl->K * pl->Opad, &pl->bwd_weight_splits);
+        pl->bwd_weight_target = pick_target_steps(cw, T, 16, 4.0 * pl->K * pl->Opad * G, &pl->bwd_weight_splits);
     }
     if (want_pix_major(g, b, PM_BWD_DATA)) {     // bwd-data: one class per input position; a tap holds n_ob steps
         LiveClass cls[16]; const int plane = g->H * g->W;
-        const long long tiles_per_pos = (long long)ceil_div(g->B, 128) * bd.tiles_c;
+        const long long tiles_per_pos = (long long)ceil_div(g->B, 128) * bd.tiles_c * G;
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_in(g, hw) * bd.n_ob};
-        pl->bwd_data_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->C * g->H * g->W, &pl->bwd_data_splits);
+        pl->bwd_data_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->C * g->H * g->W * G, &pl->bwd_data_splits);
     }
     return 0;
 }
@@ -1304,19 +1342,20 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
 
 template <int G>
 void launch_in_fwd(hipStream_t st, int planes, const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma,
-                   const float* beta, const float* a, float* y, float* mean, float* rstd, int Cn, int HW, long long bs, float eps) {
+                   const float* beta, const float* a, float* y, float* mean, float* rstd, int Cn, int HW, long long bs, float eps, int span) {
     int ppb = 256 / G;
     hipLaunchKernelGGL((k_in_prelu_fwd<G>), dim3(ceil_div(planes, ppb)), dim3(256), 0, st, z, n_slabs, slab_elems, z_out, gamma, beta, a, y,
-                       mean, rstd, planes, Cn, HW, bs, eps);
+                       mean, rstd, planes, Cn, HW, bs, eps, span);
 }
 template <int G>
 void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
-                   const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW, long long bs) {
+                   const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW, long long bs,
+                   int span) {
     int ppb = 256 / G;
     int blocks = ceil_div(planes, ppb);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
-                       dbeta, dprelu, planes, Cn, HW, bs);
+                       dbeta, dprelu, planes, Cn, HW, bs, span);
 }
 int group_lanes(int HW) { int g = 4; while (g < 64 && g < HW) g <<= 1; return g; }
 
@@ -1339,25 +1378,31 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
     const int hb = b->act != KAN_ACT_NONE;
     if ((hb && !w_base) || !w_basis || !wp) return fail("null weight pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int T = g->kh * g->kw, NI = g->C * T;
+    const int T = g->kh * g->kw, NI = g->C * T, G = ngroups(g);
+    const long long wp_gs = (long long)pl.Kpad * pl.Opad;          // floats per group in wp
     PackGeo q = pack_geo(g, b, pl, false);
     // rows no source element maps to must be zero: pad rows of every chunk, and the missing items of the last chunk
     if (pl.KC != pl.IPC * pl.P) {                       // (whole-buffer clear only for P that do not divide the step)
         if (hipMemsetAsync(wp, 0, (size_t)pl.packed_weight_bytes, st) != hipSuccess) return fail("memset failed");
     } else if (NI % pl.IPC != 0) {
-        size_t off = (size_t)(pl.Kpad - pl.KC) * pl.Opad;
-        if (hipMemsetAsync(wp + off, 0, (size_t)pl.KC * pl.Opad * 4, st) != hipSuccess) return fail("memset failed");
+        if (G > 1) {                                        // one clear instead of G small ones
+            if (hipMemsetAsync(wp, 0, (size_t)pl.packed_weight_bytes, st) != hipSuccess) return fail("memset failed");
+        } else {
+            size_t off = (size_t)(pl.Kpad - pl.KC) * pl.Opad;
+            if (hipMemsetAsync(wp + off, 0, (size_t)pl.KC * pl.Opad * 4, st) != hipSuccess) return fail("memset failed");
+        }
     }
     if (hb) {
-        dim3 grid(ceil_div(g->C * T, 32), pl.Opad / 32);
-        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, wp, q, 0);
+        dim3 grid(ceil_div(g->C * T, 32), pl.Opad / 32, G);
+        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, wp, q, 0, wp_gs);
     }
-    dim3 grid(ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32);
-    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_basis, wp, q, 1);
+    dim3 grid(ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32, G);
+    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_basis, wp, q, 1, wp_gs);
     if (wd) {
         BdCfg c = bd_cfg(g, pl);
-        dim3 gd(c.tiles_c * 4, c.Opad32 / 32, T);
-        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CH, c.tiles_c, c.Opad32);
+        if ((long long)(c.Opad32 / 32) * G > 65535) return fail("groups * output blocks exceed the grid limit");
+        dim3 gd(c.tiles_c * 4, c.Opad32 / 32 * G, T);
+        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CH, c.tiles_c, c.Opad32, wp_gs);
     }
     return launch_ok("pack");
 }
@@ -1368,14 +1413,15 @@ int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const Ka
     const int hb = b->act != KAN_ACT_NONE;
     if ((hb && !dw_base) || !dw_basis || !dwp) return fail("null weight-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
-    const int T = g->kh * g->kw;
+    const int T = g->kh * g->kw, G = ngroups(g);
+    const long long dwp_gs = (long long)pl.K * pl.Opad;
     PackGeo q = pack_geo(g, b, pl, true);
     if (hb) {
-        dim3 grid(ceil_div(g->C * T, 32), ceil_div(g->O, 32));
-        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, q, 0, pl.bwd_weight_splits, pl.bwd_weight_slab_elems);
+        dim3 grid(ceil_div(g->C * T, 32), ceil_div(g->O, 32), G);
+        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, q, 0, pl.bwd_weight_splits, pl.bwd_weight_slab_elems, dwp_gs);
     }
-    dim3 grid(ceil_div(g->C * b->n_basis * T, 32), ceil_div(g->O, 32));
-    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_basis, q, 1, pl.bwd_weight_splits, pl.bwd_weight_slab_elems);
+    dim3 grid(ceil_div(g->C * b->n_basis * T, 32), ceil_div(g->O, 32), G);
+    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_basis, q, 1, pl.bwd_weight_splits, pl.bwd_weight_slab_elems, dwp_gs);
     return launch_ok("unpack");
 }
 
@@ -1397,7 +1443,8 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     if (dg.pix_major) { x = x_pm; xn = x_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(c.tiles_p, c.tiles_o, pl.fwd_splits);          // always the plan's slab count: the consumer sums exactly that many
+    if ((long long)c.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
+    dim3 grid(c.tiles_p, c.tiles_o * ngroups(g), pl.fwd_splits);   // always the plan's slab count: the consumer sums exactly that many
     int cps = dg.pix_major ? pl.fwd_target : ceil_div(c.chunks, pl.fwd_splits);
     TilePerm perm; perm.n = 0;
     if (dg.pix_major && c.tiles_p <= PERM_MAX) {             // weight of a pixel tile = its own split count (live work)
@@ -1410,7 +1457,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     }
 #define KAN_FWD(KIND, WO, WP, KCV) KAN_FWD2(KIND, 0, WO, WP, KCV)
 #define KAN_FWD2(KIND, FAST, WO, WP, KCV) \
-    hipLaunchKernelGGL((k_conv_fwd<KIND, FAST, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), perm)
+    hipLaunchKernelGGL((k_conv_fwd<KIND, FAST, WO, WP, KCV>), grid, dim3(WO * WP * 64), 0, st, x, xn, wp, z, dg, db, pl.Opad, pl.IPC, c.chunks, cps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), perm, c.tiles_o)
 #define KAN_FWD_KIND(KIND)                                                     \
     do {                                                                       \
         if (c.TO == 128 && pl.KC == 18) KAN_FWD(KIND, 2, 2, 18);               \
@@ -1447,7 +1494,8 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     if (dg.pix_major) dz = dz_pm;
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(c.tiles_p, c.tiles_c, pl.bwd_data_splits);
+    if ((long long)c.tiles_c * ngroups(g) > 65535) return fail("groups * channel tiles exceed the grid limit");
+    dim3 grid(c.tiles_p, c.tiles_c * ngroups(g), pl.bwd_data_splits);
     int cps = dg.pix_major ? pl.bwd_data_target : ceil_div(c.chunks, pl.bwd_data_splits);
     TilePerm perm; perm.n = 0;
     if (dg.pix_major && c.tiles_p <= PERM_MAX) {
@@ -1478,11 +1526,12 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     if (dg.pix_major) { x = x_pm; xn = x_pm; dz = dz_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(c.tiles_r, c.tiles_o, pl.bwd_weight_splits);
+    if ((long long)c.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
+    dim3 grid(c.tiles_r, c.tiles_o * ngroups(g), pl.bwd_weight_splits);
     int cps = dg.pix_major ? pl.bwd_weight_target : ceil_div(c.chunks, pl.bwd_weight_splits);
 #define KAN_BW(KIND, WR, WC) KAN_BW2(KIND, 0, WR, WC)
 #define KAN_BW2(KIND, FAST, WR, WC) \
-    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4))
+    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o)
 #define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
     const int fast = fast_variant(b);
 #define KAN_BW_FAST(KIND, F) do { if (c.TO == 128) KAN_BW2(KIND, F, 2, 2); else KAN_BW2(KIND, F, 4, 1); } while (0)
@@ -1511,32 +1560,32 @@ int kan_slab_reduce(const float* slabs, int n_slabs, long long slab_elems, float
 
 int kan_instnorm_prelu_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
                            const float* prelu_a, float* y, float* mean, float* rstd, int B, int Cn, int HW, long long bstride, float eps,
-                           void* stream) {
+                           int prelu_span, void* stream) {
     if (!z || !z_out || !y || !mean || !rstd || n_slabs < 1 || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_fwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
     switch (group_lanes(HW)) {
-        case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps); break;
-        case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps); break;
-        case 16: launch_in_fwd<16>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps); break;
-        case 32: launch_in_fwd<32>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps); break;
-        default: launch_in_fwd<64>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps); break;
+        case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
+        case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
+        case 16: launch_in_fwd<16>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
+        case 32: launch_in_fwd<32>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
+        default: launch_in_fwd<64>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
     }
     return launch_ok("instnorm_fwd");
 }
 
 int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                            const float* prelu_a, float* dz, float* dgamma, float* dbeta, float* dprelu, int B, int Cn, int HW,
-                           long long bstride, void* stream) {
+                           long long bstride, int prelu_span, void* stream) {
     if (!dy || !z || !mean || !rstd || !dz || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_bwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
     switch (group_lanes(HW)) {
-        case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride); break;
-        case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride); break;
-        case 16: launch_in_bwd<16>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride); break;
-        case 32: launch_in_bwd<32>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride); break;
-        default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride); break;
+        case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
+        case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
+        case 16: launch_in_bwd<16>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
+        case 32: launch_in_bwd<32>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
+        default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
     }
     return launch_ok("instnorm_bwd");
 }

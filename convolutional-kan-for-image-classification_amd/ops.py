@@ -9,8 +9,9 @@ Two differentiable entry points, both launching only hand-written HIP kernels:
                             (kan_layers.py:241-243, cheby_kan_layers.py:98).
 * ``instance_norm``      -- InstanceNorm2d alone (fast_kan_layers.py:106, norm on the input).
 
-All tensors are fp32, NCHW, on a ROCm device.  Groups (kan_layers.py:249-258) are handled
-as one launch per group on channel-offset pointers; nothing is copied or concatenated.
+All tensors are fp32, NCHW, on a ROCm device.  Groups (kan_layers.py:249-258 loops over them in
+Python) run inside the SAME launches (KanGeom.groups; the group index is folded into the grid):
+the per-group weights are stacked once per call, activations are never copied or concatenated.
 """
 from __future__ import annotations
 
@@ -68,6 +69,7 @@ def _plan_cached(spec: ConvSpec, B: int, Cg: int, H: int, W: int, Og: int, C_tot
     g.B, g.C, g.H, g.W, g.O, g.Ho, g.Wo = B, Cg, H, W, Og, Ho, Wo
     (g.kh, g.kw), (g.sh, g.sw), (g.ph, g.pw), (g.dh, g.dw) = spec.kernel, spec.stride, spec.padding, spec.dilation
     g.x_bstride, g.y_bstride = C_total * H * W, O_total * Ho * Wo
+    g.groups = spec.groups
     b = _basis_struct(spec)
     p = L.KanPlan()
     L.check(L.load().kan_plan(C.byref(g), C.byref(b), C.byref(p)), "kan_plan")
@@ -118,8 +120,8 @@ def _launch(name: str, flops: float, t: torch.Tensor, fn) -> None:
 
 
 def _conv_flops(geom, plan) -> float:
-    """Dense algorithmic FLOPs of one conv-stage launch: 2*B*O*Ho*Wo*C*P*kh*kw."""
-    return 2.0 * geom.B * geom.O * geom.Ho * geom.Wo * geom.C * plan.P * geom.kh * geom.kw
+    """Dense algorithmic FLOPs of one conv-stage launch: 2*B*O*Ho*Wo*C*P*kh*kw per group."""
+    return 2.0 * geom.B * geom.O * geom.Ho * geom.Wo * geom.C * plan.P * geom.kh * geom.kw * max(1, geom.groups)
 
 
 def _tile_tag(plan) -> str:
@@ -135,8 +137,15 @@ def _position_major(t: torch.Tensor, ch_off: int, Cn: int) -> torch.Tensor:
     return out
 
 
+def _stack(ws: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+    """Per-group weights -> one [G, ...] block (a view for G == 1)."""
+    if ws[0] is None:
+        return None
+    return ws[0].unsqueeze(0) if len(ws) == 1 else torch.stack(list(ws))
+
+
 def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True):
-    """Returns (z_slabs [S,B,O,Ho,Wo], per-group (bwd-data weight layout or None, position-major x or None), geom, basis, plan)."""
+    """Returns (z_slabs [S,B,O,Ho,Wo], (bwd-data weight layout or None, position-major x or None), geom, basis, plan)."""
     lib = L.load()
     B, Ct, H, W = x.shape
     G = spec.groups
@@ -146,22 +155,20 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     Ho, Wo = geom.Ho, geom.Wo
     st = _stream(x)
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
-    packed = []
-    for g in range(G):
-        wp = torch.empty(plan.packed_weight_bytes // 4, device=x.device, dtype=torch.float32)
-        wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=x.device, dtype=torch.float32) if need_dgrad else None
-        L.check(lib.kan_pack_weights(_ptr(w_base[g]), _ptr(w_basis[g]), _ptr(wp), _ptr(wd), C.byref(geom), C.byref(basis), st),
-                "kan_pack_weights")
-        x_pm = _position_major(x, g * Cg, Cg) if (plan.x_pm_wanted and xn is None) else None
-        _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
-                lambda: lib.kan_conv_fwd(_ptr(x, g * Cg * H * W), _ptr(xn if xn is not None else x, g * Cg * H * W), _ptr(wp),
-                                         _ptr(z, g * Og * Ho * Wo), C.byref(geom), C.byref(basis), _ptr(x_pm), st))
-        packed.append((wd, x_pm))
-    return z, packed, geom, basis, plan
+    wp = torch.empty(plan.packed_weight_bytes // 4, device=x.device, dtype=torch.float32)
+    wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=x.device, dtype=torch.float32) if need_dgrad else None
+    wb_all, ws_all = _stack(w_base), _stack(w_basis)          # keep the stacked copies alive until the pack is enqueued
+    L.check(lib.kan_pack_weights(_ptr(wb_all), _ptr(ws_all), _ptr(wp), _ptr(wd), C.byref(geom), C.byref(basis), st), "kan_pack_weights")
+    del wb_all, ws_all
+    x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
+    _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+            lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),
+                                     _ptr(x_pm), st))
+    return z, (wd, x_pm), geom, basis, plan
 
 
 def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool):
-    """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list)."""
+    """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list) -- per-group views of stacked gradients."""
     lib = L.load()
     B, Ct, H, W = x.shape
     G = spec.groups
@@ -169,37 +176,33 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     Ot = dz.shape[1]
     Og = Ot // G
     geom, basis, plan = _plan_cached(spec, B, Cg, H, W, Og, Ct, Ot)
-    Ho, Wo = geom.Ho, geom.Wo
     kh, kw = spec.kernel
     st = _stream(x)
     xs = xn if xn is not None else x
+    wd, x_pm = packed
     dw_base: List[Optional[torch.Tensor]] = [None] * G
     dw_basis: List[Optional[torch.Tensor]] = [None] * G
-    dz_pm = [None] * G
-    if plan.dz_pm_wanted and xn is None:
-        dz_pm = [_position_major(dz, g * Og, Og) for g in range(G)]
+    dz_pm = _position_major(dz, 0, Ot) if (plan.dz_pm_wanted and xn is None) else None
     if need_w:
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
-        for g in range(G):
-            _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
-                    lambda: lib.kan_conv_bwd_weight(_ptr(dz, g * Og * Ho * Wo), _ptr(x, g * Cg * H * W), _ptr(xs, g * Cg * H * W),
-                                                    _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(packed[g][1]), _ptr(dz_pm[g]), st))
-            if spec.has_base:
-                dw_base[g] = torch.empty((Og, Cg, kh, kw), device=x.device, dtype=torch.float32)
-            dw_basis[g] = torch.empty((Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
-            L.check(lib.kan_unpack_wgrad(_ptr(dwp), _ptr(dw_base[g]), _ptr(dw_basis[g]), C.byref(geom), C.byref(basis), st), "kan_unpack_wgrad")
+        _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+                lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
+                                                _ptr(dz_pm), st))
+        dwb = torch.empty((G, Og, Cg, kh, kw), device=x.device, dtype=torch.float32) if spec.has_base else None
+        dws = torch.empty((G, Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
+        L.check(lib.kan_unpack_wgrad(_ptr(dwp), _ptr(dwb), _ptr(dws), C.byref(geom), C.byref(basis), st), "kan_unpack_wgrad")
+        dw_basis = list(dws.unbind(0))
+        if spec.has_base:
+            dw_base = list(dwb.unbind(0))
     dx = dxn = None
     if need_x or need_xn:
         S = plan.bwd_data_splits
         separate = xn is not None
         dxs = torch.empty((S, B, Ct, H, W), device=x.device, dtype=torch.float32)
         dxns = torch.empty_like(dxs) if separate else None
-        for g in range(G):
-            off = g * Cg * H * W
-            _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
-                    lambda: lib.kan_conv_bwd_data(_ptr(dz, g * Og * Ho * Wo), _ptr(x, off), _ptr(xs, off), _ptr(packed[g][0]),
-                                                  _ptr(dxs, off), _ptr(dxns, off) if separate else C.c_void_p(0),
-                                                  C.byref(geom), C.byref(basis), _ptr(dz_pm[g]), st))
+        _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
+                lambda: lib.kan_conv_bwd_data(_ptr(dz), _ptr(x), _ptr(xs), _ptr(wd), _ptr(dxs), _ptr(dxns) if separate else C.c_void_p(0),
+                                              C.byref(geom), C.byref(basis), _ptr(dz_pm), st))
         dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
     return dx, dxn, dw_base, dw_basis
 
@@ -215,11 +218,10 @@ def _sum_slabs(slabs: torch.Tensor, B: int, Cn: int, HW: int) -> torch.Tensor:
 
 
 def _unflatten(layout, tensors):
-    """Inverse of the save_for_backward flattening of the per-group (wd, x_pm) pairs."""
-    out, it = [], iter(tensors)
-    for has_wd, has_xp in layout:
-        out.append((next(it) if has_wd else None, next(it) if has_xp else None))
-    return out
+    """Inverse of the save_for_backward flattening of the (wd, x_pm) pair."""
+    it = iter(tensors)
+    has_wd, has_xp = layout
+    return (next(it) if has_wd else None, next(it) if has_xp else None)
 
 
 def _flat_grads(spec: ConvSpec, dw_base, dw_basis):
@@ -241,8 +243,8 @@ class _KanConv(torch.autograd.Function):
             z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis, need_dgrad)
             z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
         ctx.spec, ctx.has_xn = spec, xn is not None
-        ctx.layout = [(wd is not None, xp is not None) for wd, xp in packed]
-        ctx.save_for_backward(x, *([xn] if xn is not None else []), *[t for pair in packed for t in pair if t is not None])
+        ctx.layout = (packed[0] is not None, packed[1] is not None)
+        ctx.save_for_backward(x, *([xn] if xn is not None else []), *[t for t in packed if t is not None])
         return z
 
     @staticmethod
@@ -256,6 +258,13 @@ class _KanConv(torch.autograd.Function):
         with torch.cuda.device(x.device):
             dx, dxn, dwb, dws = _conv_backward(ctx.spec, x, xn, packed, dz.contiguous(), need_x, need_xn, need_w)
         return (None, dx if need_x else None, dxn if need_xn else None) + _flat_grads(ctx.spec, dwb, dws)
+
+
+def _cat(ts: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
+    """Per-group vectors -> one contiguous vector (the tensor itself for one group)."""
+    if ts[0] is None:
+        return None
+    return ts[0] if len(ts) == 1 else torch.cat([t.reshape(-1) for t in ts])
 
 
 class _KanConvInPrelu(torch.autograd.Function):
@@ -282,19 +291,17 @@ class _KanConvInPrelu(torch.autograd.Function):
             S, B, Ot, Ho, Wo = zs.shape
             Og, HW = Ot // G, Ho * Wo
             y = torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
-            mean = torch.empty((G, B * Og), device=x.device, dtype=torch.float32)
+            mean = torch.empty(B * Ot, device=x.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
-            st = _stream(x)
-            for g in range(G):
-                off = g * Og * HW
-                L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs, off), S, plan.fwd_slab_elems, _ptr(zs, off), _ptr(gammas[g]), _ptr(betas[g]),
-                                                   _ptr(prelus[g]), _ptr(y, off), _ptr(mean, g * B * Og), _ptr(rstd, g * B * Og),
-                                                   B, Og, HW, Ot * HW, eps, st), "kan_instnorm_prelu_fwd")
+            # all groups in one launch: per-channel gamma/beta concatenated, one PReLU slope per Og channels
+            gamma, beta, slope = _cat(gammas), _cat(betas), _cat(prelus)
+            L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(zs), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(y),
+                                               _ptr(mean), _ptr(rstd), B, Ot, HW, Ot * HW, eps, Og if G > 1 else 0, _stream(x)),
+                    "kan_instnorm_prelu_fwd")
         z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
         ctx.spec, ctx.flags = spec, (use_affine, use_prelu)
-        ctx.layout = [(wd is not None, xp is not None) for wd, xp in packed]
-        ctx.save_for_backward(x, z, mean, rstd, *[t for pair in packed for t in pair if t is not None],
-                              *[t for t in list(gammas) + list(betas) + list(prelus) if t is not None])
+        ctx.layout = (packed[0] is not None, packed[1] is not None)
+        ctx.save_for_backward(x, z, mean, rstd, *[t for t in packed if t is not None], *[t for t in (gamma, beta, slope) if t is not None])
         return y
 
     @staticmethod
@@ -305,35 +312,31 @@ class _KanConvInPrelu(torch.autograd.Function):
         G = spec.groups
         saved = ctx.saved_tensors
         x, z, mean, rstd = saved[:4]
-        nwd = sum(int(a) + int(b) for a, b in ctx.layout)
+        nwd = int(ctx.layout[0]) + int(ctx.layout[1])
         packed = _unflatten(ctx.layout, list(saved[4:4 + nwd]))
         rest = list(saved[4 + nwd:])
-        gammas = rest[:G] if use_affine else [None] * G
-        betas = rest[G:2 * G] if use_affine else [None] * G
-        prelus = rest[2 * G * int(use_affine):] if use_prelu else [None] * G
+        gamma, beta = (rest[0], rest[1]) if use_affine else (None, None)
+        slope = rest[2 * int(use_affine)] if use_prelu else None
         dy = dy.contiguous()
         B, Ot, Ho, Wo = dy.shape
         Og, HW = Ot // G, Ho * Wo
         with torch.cuda.device(x.device):
-            st = _stream(x)
             dz = torch.empty_like(dy)
-            dgam = [torch.zeros_like(t) for t in gammas] if use_affine else [None] * G
-            dbet = [torch.zeros_like(t) for t in betas] if use_affine else [None] * G
-            dpre = [torch.zeros_like(t) for t in prelus] if use_prelu else [None] * G
-            for g in range(G):
-                off = g * Og * HW
-                L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy, off), _ptr(z, off), _ptr(mean, g * B * Og), _ptr(rstd, g * B * Og),
-                                                   _ptr(gammas[g]), _ptr(betas[g]), _ptr(prelus[g]), _ptr(dz, off),
-                                                   _ptr(dgam[g]), _ptr(dbet[g]), _ptr(dpre[g]), B, Og, HW, Ot * HW, st), "kan_instnorm_prelu_bwd")
+            dgam = torch.zeros_like(gamma) if use_affine else None
+            dbet = torch.zeros_like(beta) if use_affine else None
+            dpre = torch.zeros_like(slope) if use_prelu else None
+            L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(dz),
+                                               _ptr(dgam), _ptr(dbet), _ptr(dpre), B, Ot, HW, Ot * HW, Og if G > 1 else 0, _stream(x)),
+                    "kan_instnorm_prelu_bwd")
             nw = G * (2 if spec.has_base else 1)
             need_x = ctx.needs_input_grad[4]
             need_w = any(ctx.needs_input_grad[5:5 + nw])
             dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w)
         grads = _flat_grads(spec, dwb, dws)
         if use_affine:
-            grads += tuple(dgam) + tuple(dbet)
+            grads += tuple(dgam.view(G, Og).unbind(0)) + tuple(dbet.view(G, Og).unbind(0))
         if use_prelu:
-            grads += tuple(dpre)
+            grads += tuple(dpre.view(G, 1).unbind(0))
         return (None, None, None, None, dx if need_x else None) + grads
 
 
@@ -350,7 +353,7 @@ class _InstanceNorm(torch.autograd.Function):
             mean = torch.empty(B * Cn, device=x.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
             L.check(lib.kan_instnorm_prelu_fwd(_ptr(x), 1, 0, _ptr(x), _ptr(gamma), _ptr(beta), C.c_void_p(0), _ptr(y), _ptr(mean), _ptr(rstd),
-                                               B, Cn, H * W, Cn * H * W, eps, _stream(x)), "kan_instnorm_prelu_fwd")
+                                               B, Cn, H * W, Cn * H * W, eps, 0, _stream(x)), "kan_instnorm_prelu_fwd")
         ctx.affine = gamma is not None
         ctx.save_for_backward(x, mean, rstd, *([gamma, beta] if gamma is not None else []))
         return y
@@ -368,7 +371,7 @@ class _InstanceNorm(torch.autograd.Function):
             dg = torch.zeros_like(gamma) if ctx.affine else None
             db = torch.zeros_like(beta) if ctx.affine else None
             L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), C.c_void_p(0), _ptr(dx),
-                                               _ptr(dg), _ptr(db), C.c_void_p(0), B, Cn, H * W, Cn * H * W, _stream(x)), "kan_instnorm_prelu_bwd")
+                                               _ptr(dg), _ptr(db), C.c_void_p(0), B, Cn, H * W, Cn * H * W, 0, _stream(x)), "kan_instnorm_prelu_bwd")
         return dx, dg, db, None
 
 

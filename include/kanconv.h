@@ -15,9 +15,12 @@
  *   - return value: 0 on success, <0 on error; message via kan_last_error() (thread-local);
  *   - no C++ exception crosses the boundary; no mutable global state.
  *
- * Tensor layouts: activations NCHW; one "group" of the reference layer per call, so a
- * grouped layer is G calls whose x / y pointers are offset by the group's first channel
- * and whose batch strides (`x_bstride`, `y_bstride`) are those of the FULL tensors.
+ * Tensor layouts: activations NCHW.  KanGeom describes ONE group of the reference layer
+ * (kan_layers.py:249-258 loops over groups in Python); `groups` = G > 1 runs G such groups in
+ * the same launches: group j reads channels [j*C, (j+1)*C) of x and writes channels
+ * [j*O, (j+1)*O) of z, x / z point at group 0's first channel and the batch strides
+ * (`x_bstride`, `y_bstride`) are those of the FULL tensors.  Per-group weights are stacked on a
+ * leading axis; every packed / workspace layout is G per-group blocks back to back.
  */
 #ifndef KANCONV_H
 #define KANCONV_H
@@ -40,6 +43,7 @@ typedef struct KanGeom {
     int B, C, H, W;              /* input block: batch, channels of this group, height, width */
     int O, Ho, Wo;               /* output block of this group */
     int kh, kw, sh, sw, ph, pw, dh, dw;
+    int groups;                  /* G groups handled by one call (0 is read as 1); C and O stay PER GROUP */
     long long x_bstride;         /* distance between images in x / dx  (C_total*H*W)   */
     long long y_bstride;         /* distance between images in z / dz  (O_total*Ho*Wo) */
 } KanGeom;
@@ -73,11 +77,11 @@ typedef struct KanPlan {
     int fwd_target, bwd_data_target, bwd_weight_target;   /* position-major launches: live steps per split (0 = n/a) */
     int x_pm_wanted, dz_pm_wanted;/* small padded planes: pass position-major copies (kan_position_major) of x / dz to
                                      unlock structural-zero tap skipping; optional, NULL keeps the image-major path */
-    long long packed_weight_bytes;    /* Kpad*Opad*4 */
-    long long bwd_data_weight_bytes;  /* size of the bwd-data weight layout `wd` */
+    long long packed_weight_bytes;    /* G*Kpad*Opad*4    : all groups, group j at j*Kpad*Opad floats */
+    long long bwd_data_weight_bytes;  /* size of the bwd-data weight layout `wd`, all groups (equal blocks) */
     long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */
     long long bwd_data_slab_elems;    /* B*x_bstride      : stride between dx slabs */
-    long long bwd_weight_slab_elems;  /* K*Opad           : stride between dW slabs */
+    long long bwd_weight_slab_elems;  /* G*K*Opad         : stride between dW slabs, group j at j*K*Opad inside a slab */
 } KanPlan;
 
 const char* kan_version(void);
@@ -95,7 +99,8 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
  * Replaces nothing in the reference (layout only); sources are  base_conv[g].weight [O,C,kh,kw]  (kan_layers.py:159-166) and
  * spline_conv[g].weight / poly_conv[g].weight [O,C*n_basis,kh,kw], channel c*n_basis+k
  * (kan_layers.py:170-177,237; fast_kan_layers.py:68-75,107; cheby_kan_layers.py:77-84,95).
- * `w_base` may be NULL iff basis->act == KAN_ACT_NONE. */
+ * `w_base` may be NULL iff basis->act == KAN_ACT_NONE.  With geom->groups = G the sources are the per-group weights
+ * stacked on a leading axis, [G,O,C,kh,kw] and [G,O,C*n_basis,kh,kw]. */
 int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float* wd,
                      const KanGeom* geom, const KanBasis* basis, void* stream);
 
@@ -111,8 +116,8 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
 int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z,
                  const KanGeom* geom, const KanBasis* basis, const float* x_pm, void* stream);
 
-/* dst[(c*HW + i)*B + b] = src[b*bstride + c*HW + i]  (B images, Cn channels of HW pixels): the position-major copy
- * the conv kernels read on small padded planes, where whole taps are structurally zero for a given output position
+/* dst[(c*HW + i)*B + b] = src[b*bstride + c*HW + i]  (B images, Cn channels of HW pixels; Cn = G*C or G*O of a grouped
+ * call): the position-major copy the conv kernels read on small padded planes, where whole taps are structurally zero for a given output position
  * (the reference multiplies those zeros: kan_layers.py:239 zero-pads the expanded tensor). */
 int kan_position_major(const float* src, float* dst, int B, int Cn, int HW, long long bstride, void* stream);
 
@@ -130,8 +135,8 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
 int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,
                         const KanGeom* geom, const KanBasis* basis, const float* x_pm, const float* dz_pm, void* stream);
 
-/* Sum the dwp slabs and scatter back to the reference layouts (inverse of kan_pack_weights).
- * dw_base may be NULL iff there is no base branch. */
+/* Sum the dwp slabs and scatter back to the reference layouts (inverse of kan_pack_weights; stacked [G,...] when
+ * geom->groups = G).  dw_base may be NULL iff there is no base branch. */
 int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis,
                      const KanGeom* geom, const KanBasis* basis, void* stream);
 
@@ -144,19 +149,21 @@ int kan_slab_reduce(const float* slabs, int n_slabs, long long slab_elems, float
  * (layer_norm -> prelus), cheby_kan_layers.py:98 and fast_kan_layers.py:106 (norm only:
  * pass prelu_a = NULL).  `z` holds n_slabs partial slabs (their sum is normalised); the
  * summed pre-norm value is written to z_out (may alias slab 0), which the backward needs.
- * mean / rstd: [B*Cn] outputs saved for the backward. */
+ * mean / rstd: [B*Cn] outputs saved for the backward.
+ * prelu_span: 0 = one slope prelu_a[0] for every channel (nn.PReLU()); k > 0 = channel c uses prelu_a[c / k] -- the
+ * per-group slopes prelus[g] of a grouped layer (kan_layers.py:182,243) concatenated, k = channels per group. */
 int kan_instnorm_prelu_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out,
                            const float* gamma, const float* beta, const float* prelu_a,
                            float* y, float* mean, float* rstd,
-                           int B, int Cn, int HW, long long bstride, float eps, void* stream);
+                           int B, int Cn, int HW, long long bstride, float eps, int prelu_span, void* stream);
 
 /* Backward of the above.  dz <- gradient w.r.t. the summed pre-norm value.
- * dgamma/dbeta ([Cn]) and dprelu ([1]) are ACCUMULATED with atomics: zero them first.
+ * dgamma/dbeta ([Cn]) and dprelu ([1], or [Cn / prelu_span]) are ACCUMULATED with atomics: zero them first.
  * Any of gamma/prelu_a/dgamma/dbeta/dprelu may be NULL when that feature is off. */
 int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, const float* rstd,
                            const float* gamma, const float* beta, const float* prelu_a,
                            float* dz, float* dgamma, float* dbeta, float* dprelu,
-                           int B, int Cn, int HW, long long bstride, void* stream);
+                           int B, int Cn, int HW, long long bstride, int prelu_span, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,40 @@ def test_edge_shapes_vs_oracle(case, gpu_lib):
     _compare(layer, _cfg("bspline", case["C"], case["O"], k=k, s=s, p=p, d=d, groups=G), x, tol_scale=2.0)
 
 
+GROUPED = [
+    # (kind, C, O, groups, H, B, extra layer kwargs) -- every group runs in the same launches (KanGeom.groups)
+    ("bspline", 64, 160, 2, 12, 8, {}),                     # several pixel tiles, ragged 80-output groups
+    ("bspline", 40, 40, 40, 14, 16, dict(affine=True)),     # depthwise (kan_mobilenetv2.py:253-255 replace_depthwise), per-group gamma/beta
+    ("bspline", 32, 32, 4, 2, 32, {}),                      # position-major 2x2 planes: tap skipping with group offsets
+    ("bspline", 32, 48, 2, 4, 32, {}),                      # position-major weight gradient on 4x4 planes
+    ("bspline", 24, 24, 24, 4, 64, {}),                     # depthwise on 4x4 planes
+    ("rbf", 48, 96, 3, 9, 4, {}),
+    ("cheby", 30, 60, 5, 7, 6, dict(affine=True)),
+]
+
+
+@pytest.mark.parametrize("case", GROUPED, ids=lambda c: f"{c[0]}-C{c[1]}-O{c[2]}-g{c[3]}-{c[4]}x{c[4]}")
+def test_grouped_single_launch_vs_oracle(case, gpu_lib):
+    kind, C, O, G, H, B, kw = case
+    torch.manual_seed(C + G)
+    if kind == "bspline":
+        layer = K.KANConv2DLayer(C, O, 3, groups=G, padding=1, base_activation=nn.SiLU, **kw)
+        cfg = _cfg("bspline", C, O, groups=G, act="silu")
+    elif kind == "rbf":
+        layer = K.FastKANConv2DLayer(C, O, 3, groups=G, padding=1, **kw)
+        cfg = _cfg("rbf", C, O, groups=G)
+    else:
+        layer = K.ChebyKANConv2DLayer(C, O, 3, groups=G, padding=1, degree=3, **kw)
+        cfg = _cfg("cheby", C, O, groups=G, degree=3)
+    with torch.no_grad():                                   # distinct per-group norm / PReLU parameters
+        for n, p in layer.named_parameters():
+            if "prelus" in n:
+                p.fill_(0.05 + 0.03 * int(n.split(".")[1]))
+            elif "layer_norm" in n:
+                p.add_(0.2 * torch.randn_like(p))
+    _compare(layer, cfg, torch.randn(B, C, H, H), tol_scale=8.0 if H == 2 else 2.0)
+
+
 def test_nan_and_out_of_grid_inputs(gpu_lib):
     """x outside the knot span has all bases zero (kan_layers.py:209); NaN inputs propagate through the base branch only."""
     torch.manual_seed(1)

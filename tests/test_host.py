@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(L.KanGeom) == 15 * 4 + 4 + 16          # 15 ints, pad, 2 x int64
+    assert ctypes.sizeof(L.KanGeom) == 16 * 4 + 16              # 16 ints (incl. groups), 2 x int64
+    assert L.KanGeom.groups.offset == 60 and L.KanGeom.x_bstride.offset == 64
     assert ctypes.sizeof(L.KanBasis) == 4 * 4 + 2 * 4 + 32 * 4
     assert ctypes.sizeof(L.KanPlan) == 14 * 4 + 5 * 8
 
@@ -54,6 +55,20 @@ def test_plan_arithmetic():
     assert p.Opad == 64 and p.P == 9
     g, b, p = _plan(3, 64, 224, k=11, p=2, s=4, kind=L.BASIS_CHEBY, nb=5, act=L.ACT_NONE)
     assert (g.Ho, g.Wo) == (55, 55) and p.P == 5 and p.KC == 16 and p.IPC == 3
+
+
+def test_plan_with_groups_scales_per_group_blocks():
+    table = tuple(float(v) for v in torch.linspace(-2.2, 2.2, 12).tolist())
+    mk = lambda G: ops.ConvSpec(kind=L.BASIS_BSPLINE, n_basis=8, order=3, act=L.ACT_SILU, p0=0.0, p1=0.0, table=table, kernel=(3, 3),
+                                stride=(1, 1), padding=(1, 1), dilation=(1, 1), groups=G)
+    g1, _, p1 = ops._plan_cached(mk(1), 8, 16, 14, 14, 24, 16, 24)
+    g4, _, p4 = ops._plan_cached(mk(4), 8, 16, 14, 14, 24, 64, 96)        # 4 groups of the same per-group geometry
+    assert (g1.groups, g4.groups) == (1, 4) and (p4.K, p4.Kpad, p4.Opad) == (p1.K, p1.Kpad, p1.Opad)      # per-group dims
+    assert p4.packed_weight_bytes == 4 * p1.packed_weight_bytes and p4.bwd_data_weight_bytes == 4 * p1.bwd_data_weight_bytes
+    assert p4.bwd_weight_slab_elems == 4 * p1.bwd_weight_slab_elems
+    assert p4.fwd_slab_elems == 8 * 96 * 14 * 14 and p4.bwd_data_slab_elems == 8 * 64 * 14 * 14
+    with pytest.raises(L.KanConvError, match="batch stride"):
+        ops._plan_cached(mk(4), 8, 16, 14, 14, 24, 16, 96)                # x_bstride of one group only
 
 
 def test_plan_rejects_bad_inputs():

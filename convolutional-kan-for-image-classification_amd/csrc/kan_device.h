@@ -160,6 +160,32 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
                 v[p] = DERIV ? e * (-2.0f * u) / dn : e;
             }
         }
+    } else if (KIND == KAN_BASIS_POLY) {
+        // Three-term-recurrence families (bessel / fibonacci / gegenbauer / hermite / laguerre / lucas / taylor / jacobi
+        // _kan_layers.py, compute_*_basis): on t = tanh(x) (order = 1) or t = x (order = 0),
+        //   T_0 = c0,  T_1 = a1 t + b1,  T_k = (A_k t + B_k) T_{k-1} + C_k T_{k-2}   (k >= 2)
+        // with the per-family coefficients precomputed on the host: tab = [c0, a1, b1, A_2, B_2, C_2, A_3, ...].
+        // The derivative runs the differentiated recurrence alongside: T_k' = A_k T_{k-1} + (A_k t + B_k) T_{k-1}' + C_k T_{k-2}'.
+        const float t = bs.order ? tanhf(xb) : xb;
+        const float chain = bs.order ? (1.0f - t * t) : 1.0f;
+        float Tm = tabs[0], Tc = tabs[1] * t + tabs[2];
+        float Dm = 0.f, Dc = tabs[1];
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p) {
+            const int k = p - hb;
+            if (k >= 0 && k < bs.nb) {
+                if (k == 0) v[p] = DERIV ? 0.f : Tm;
+                else {
+                    v[p] = DERIV ? Dc * chain : Tc;
+                    if (k + 1 < bs.nb) {
+                        const float A = tabs[3 * k], B = tabs[3 * k + 1], Cc = tabs[3 * k + 2];      // coefficients of T_{k+1}
+                        const float s = A * t + B;
+                        const float Tn = s * Tc + Cc * Tm, Dn = A * Tc + s * Dc + Cc * Dm;
+                        Tm = Tc; Tc = Tn; Dm = Dc; Dc = Dn;
+                    }
+                }
+            }
+        }
     } else {
         // cheby_kan_layers.py:93-96  T_k = cos(k * acos(t)), t = clamp(tanh x, lo, hi), evaluated by the three-term
         // recurrence T_k = 2 t T_{k-1} - T_{k-2} (max |delta| 9.8e-7 vs the reference for

@@ -1067,7 +1067,8 @@ int check(const KanGeom* g, const KanBasis* b) {
         return fail("activation tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     if (g->x_bstride < (long long)ngroups(g) * g->C * g->H * g->W || g->y_bstride < (long long)ngroups(g) * g->O * g->Ho * g->Wo)
         return fail("batch stride smaller than groups * channels * plane");
-    if (b->kind < 0 || b->kind > 2) return fail("unknown basis kind");
+    if (b->kind < 0 || b->kind > KAN_BASIS_POLY) return fail("unknown basis kind");
+    if (b->kind == KAN_BASIS_POLY && (b->n_basis > 11 || b->order < 0 || b->order > 1)) return fail("bad recurrence-basis parameters");
     if (b->act < KAN_ACT_NONE || b->act > KAN_ACT_GELU_TANH) return fail("unknown activation");
     int P = b->n_basis + (b->act != KAN_ACT_NONE);
     if (b->n_basis < 1 || P > KAN_MAX_PLANES) return fail("planes per channel exceed KAN_MAX_PLANES");
@@ -1474,6 +1475,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     else if (fast == 5) KAN_FWD_FAST(KAN_BASIS_CHEBY, 5, 16);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
+    else if (b->kind == KAN_BASIS_POLY) KAN_FWD_KIND(KAN_BASIS_POLY);
     else KAN_FWD_KIND(KAN_BASIS_CHEBY);
 #undef KAN_FWD_FAST
 #undef KAN_FWD_KIND
@@ -1510,6 +1512,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
     if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
+    else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
     else KAN_BD(KAN_BASIS_CHEBY);
 #undef KAN_BD
     return launch_ok("conv_bwd_data");
@@ -1542,6 +1545,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     else if (fast == 5) KAN_BW_FAST(KAN_BASIS_CHEBY, 5);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
+    else if (b->kind == KAN_BASIS_POLY) KAN_BW_KIND(KAN_BASIS_POLY);
     else KAN_BW_KIND(KAN_BASIS_CHEBY);
 #undef KAN_BW_FAST
 #undef KAN_BW_KIND

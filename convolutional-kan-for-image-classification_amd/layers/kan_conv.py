@@ -1,15 +1,19 @@
 """Factory functions with the reference's signatures (layers/kan_conv.py:27-69, 197-276, 726-745).
 
 ``CONV_KAN_FACTORY[name](in_planes, out_planes, kernel_size=..., ...)`` is the drop-in boundary the
-reference's models use (models/kan_vgg.py:73-101, models/kan_alexnet.py:54-69).  Only the three
-basis families on the accelerated path (plus the plain ``conv`` helper) are registered; the other
-14 families of the reference are out of scope.
+reference's models use (models/kan_vgg.py:73-101, models/kan_alexnet.py:54-69).  Registered: the three
+basis families of the hot path, the eight three-term-recurrence polynomial families of SURVEY.md
+section 8(f) rank 3 (Bessel, Fibonacci, Gegenbauer, Hermite, Jacobi, Laguerre, Lucas, Taylor) and the
+plain ``conv`` helper.  Not built: Legendre (batch-global min/max normalisation), GRAM, Wav, Bernstein,
+Fourier, ReLU-KAN.
 """
 from typing import Callable, List, Optional, Tuple, Union
 
 import torch.nn as nn
 
 from .conv_layers import ChebyKANConv2DLayer, FastKANConv2DLayer, KANConv2DLayer
+from .poly_layers import (BesselKANConv2DLayer, FibonacciKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
+                          JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 
 _IntOrPair = Union[int, Tuple[int, int]]
 
@@ -87,9 +91,117 @@ def conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int =
     return nn.Sequential(*mods)
 
 
+# ---- three-term-recurrence polynomial families.  As in the reference (kan_conv.py:354-724) `dilation` only enters the
+# 'same' padding and is NOT forwarded to the layer, and `l1_decay` travels in **norm_kwargs where the signature filter
+# drops it (Taylor: not forwarded at all).
+def besselkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                   dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                   degree: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                   norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> BesselKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return BesselKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                                padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
+                                norm_layer=norm_layer, **norm_kwargs)
+
+
+def fibonaccikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                      dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                      degree: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                      norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> FibonacciKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return FibonacciKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                                   padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
+                                   norm_layer=norm_layer, **norm_kwargs)
+
+
+def gegenbauerkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                       dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                       degree: int = 3, alpha_param: float = 0.0, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                       norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> GegenbauerKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return GegenbauerKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                                    padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, alpha_param=alpha_param,
+                                    base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+
+
+def hermitekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                    dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                    degree: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                    norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> HermiteKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return HermiteKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                                 padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
+                                 norm_layer=norm_layer, **norm_kwargs)
+
+
+def jacobikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                   dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                   degree: int = 3, a: float = 1.0, b: float = 1.0, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                   norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> JacobiKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return JacobiKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, a=a, b=b,
+                                groups=groups, padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout,
+                                base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+
+
+def laguerrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                     dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                     degree: int = 3, alpha: float = 1.0, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                     norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> LaguerreKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return LaguerreKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, alpha=alpha,
+                                  groups=groups, padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout,
+                                  base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+
+
+def lucaskan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                  dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                  degree: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                  norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> LucasKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return LucasKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                               padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
+                               norm_layer=norm_layer, **norm_kwargs)
+
+
+def taylorkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                   dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                   degree: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                   norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> TaylorKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return TaylorKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                                padding=padding, stride=stride, dropout=dropout, base_activation=base_activation, norm_layer=norm_layer,
+                                **norm_kwargs)
+
+
+
 CONV_KAN_FACTORY = {
     "KAN": kan_conv,
     "FastKAN": fastkan_conv,
     "ChebyKAN": chebykan_conv,
+    "BesselKAN": besselkan_conv,
+    "FibonacciKAN": fibonaccikan_conv,
+    "GegenbauerKAN": gegenbauerkan_conv,
+    "HermiteKAN": hermitekan_conv,
+    "JacobiKAN": jacobikan_conv,
+    "LaguerreKAN": laguerrekan_conv,
+    "LucasKAN": lucaskan_conv,
+    "TaylorKAN": taylorkan_conv,
     "conv": conv,
 }

@@ -1,0 +1,345 @@
+"""Polynomial-basis conv-KAN layers whose basis is a three-term recurrence -- SURVEY.md section 8(f), "next" rank 3.
+
+  reference class (layers/...)                                this file
+  bessel_kan_layers.py:38-190      BesselKANConvNDLayer/2D      BesselKANConvNDLayer / BesselKANConv2DLayer
+  fibonacci_kan_layers.py:41-240   FibonacciKANConvNDLayer/2D   FibonacciKANConvNDLayer / FibonacciKANConv2DLayer
+  gegenbauer_kan_layers.py:..-225  GegenbauerKANConvNDLayer/2D  GegenbauerKANConvNDLayer / GegenbauerKANConv2DLayer
+  hermite_kan_layers.py:30-183     HermiteKANConvNDLayer/2D     HermiteKANConvNDLayer / HermiteKANConv2DLayer
+  laguerre_kan_layers.py:38-202    LaguerreKANConvNDLayer/2D    LaguerreKANConvNDLayer / LaguerreKANConv2DLayer
+  lucas_kan_layers.py:40-218       LucasKANConvNDLayer/2D       LucasKANConvNDLayer / LucasKANConv2DLayer
+  taylor_kan_layers.py:40-195      TaylorKANConvNDLayer/2D      TaylorKANConvNDLayer / TaylorKANConv2DLayer
+  jacobi_kan_layers.py:55-199      JacobiKANConvNDLayer/2D      JacobiKANConvNDLayer / JacobiKANConv2DLayer
+
+The first seven share one shape (e.g. lucas_kan_layers.py:176-199):
+    y = Dropout(PReLU(norm(conv(act(x), W_base) + conv(basis(tanh x), W_poly))))
+with basis planes T_0..T_degree (Taylor: x^0..x^(degree-1)) of t = tanh(x), channel index c*(degree+1)+k.  Every one of
+these bases is T_k = (A_k t + B_k) T_{k-1} + C_k T_{k-2}; the coefficients are computed here and handed to the same HIP
+conv stage as the B-spline layers (KAN_BASIS_POLY), so forward, input gradient and weight gradient are the fused kernels.
+Jacobi keeps its own structure (identity base branch, plane-major ``poly_weights``, norm then activation).
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import ops
+from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm, _need_conv2d)
+
+Coeffs = Tuple[float, float, float, List[Tuple[float, float, float]]]       # c0, a1, b1, [(A_k, B_k, C_k) for k = 2..]
+
+
+def _table(c: Coeffs, n_basis: int) -> Tuple[float, ...]:
+    c0, a1, b1, rec = c
+    out = [float(c0), float(a1), float(b1)]
+    for k in range(2, n_basis):
+        out.extend(float(v) for v in rec[k - 2])
+    return tuple(out)
+
+
+class _RecurrenceKANConvNDLayer(_HipLayer):
+    """Shared body of the seven 'base conv + polynomial conv -> norm -> PReLU' layers."""
+    _min_degree = 0
+    _min_degree_msg = 'degree must be non-negative'
+
+    def _setup(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+               base_activation, dropout, norm_kwargs, none_is_identity=True):
+        _need_conv2d(conv_class, ndim)
+        _check_groups(groups, input_dim, output_dim)
+        if degree < self._min_degree:
+            raise ValueError(self._min_degree_msg)
+        self.input_dim, self.output_dim, self.kernel_size, self.degree = input_dim, output_dim, kernel_size, degree
+        self.groups, self.padding, self.stride, self.dilation, self.ndim = groups, padding, stride, dilation, ndim
+        self.base_activation = base_activation() if (base_activation is not None or not none_is_identity) else nn.Identity()
+        self.norm_kwargs = norm_kwargs
+        self.input_dim_group, self.output_dim_group = input_dim // groups, output_dim // groups
+        self.poly_input_dim_group = self.input_dim_group * self._n_planes()
+        cg, og = self.input_dim_group, self.output_dim_group
+        self.base_conv = nn.ModuleList([conv_class(cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                        for _ in range(groups)])
+        self.poly_conv = nn.ModuleList([conv_class(self.poly_input_dim_group, og, kernel_size, stride, padding, dilation, groups=1,
+                                                   bias=False) for _ in range(groups)])
+        self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
+        self.prelus = nn.ModuleList([nn.PReLU() for _ in range(groups)])
+        self.dropout = _dropout2d(dropout)
+        for conv in self.base_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        for conv in self.poly_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        self._act_code = _act_code(self.base_activation)
+        if self._n_planes() > 11:
+            raise NotImplementedError("the HIP recurrence basis holds at most 11 planes per channel (degree <= 10)")
+
+    def _n_planes(self) -> int:
+        return self.degree + 1
+
+    def _coeffs(self) -> Coeffs:
+        raise NotImplementedError
+
+    def conv_spec(self) -> ops.ConvSpec:
+        n = self._n_planes()
+        return self._spec(kind=L.BASIS_POLY, n_basis=n, order=1, act=self._act_code, p0=0.0, p1=0.0, table=_table(self._coeffs(), n))
+
+    def forward(self, x):
+        spec = self.conv_spec()
+        wb = [m.weight for m in self.base_conv]
+        ws = [m.weight for m in self.poly_conv]
+        prelus = [m.weight for m in self.prelus]
+        if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
+            gam, bet = self._norm_affine(self.layer_norm)
+            y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
+        else:
+            z = ops.kan_conv(spec, x, None, wb, ws)
+            og = self.output_dim_group
+            y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
+        if self.dropout is not None:
+            y = self.dropout(y)
+        return y
+
+
+# ------------------------------------------------------------------------------------------- Bessel
+class BesselKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """y_0 = 1, y_1 = t + 1, y_n = (2n-1) t y_{n-1} + y_{n-2}  (bessel_kan_layers.py compute_bessel_basis)."""
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs)
+
+    def _coeffs(self):
+        return 1.0, 1.0, 1.0, [(2.0 * k - 1.0, 0.0, 1.0) for k in range(2, self.degree + 1)]
+
+
+class BesselKANConv2DLayer(BesselKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Fibonacci
+class FibonacciKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """F_0 = 0, F_1 = 1, F_n = t F_{n-1} + F_{n-2}  (fibonacci_kan_layers.py compute_fibonacci_basis)."""
+    _min_degree = 1
+    _min_degree_msg = 'degree must be at least 1'
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs)
+
+    def _coeffs(self):
+        return 0.0, 0.0, 1.0, [(1.0, 0.0, 1.0) for _ in range(2, self.degree + 1)]
+
+
+class FibonacciKANConv2DLayer(FibonacciKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Gegenbauer
+class GegenbauerKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """C_0 = 1, C_1 = 2 a t, C_{n+1} = (2 (n + a) t C_n - (n + 2a - 1) C_{n-1}) / (n + 1)  (gegenbauer_kan_layers.py)."""
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, alpha_param, groups=1, padding=0, stride=1,
+                 dilation=1, ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        if alpha_param <= -0.5:
+            raise ValueError('alpha_param must be greater than -0.5')
+        self.alpha_param = alpha_param
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs)
+
+    def _coeffs(self):
+        a = float(self.alpha_param)
+        return 1.0, 2.0 * a, 0.0, [(2.0 * (k - 1 + a) / k, 0.0, -(k + 2.0 * a - 2.0) / k) for k in range(2, self.degree + 1)]
+
+
+class GegenbauerKANConv2DLayer(GegenbauerKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, alpha_param, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, alpha_param=alpha_param, groups=groups, padding=padding, stride=stride,
+                         dilation=dilation, ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Hermite
+class HermiteKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """H_0 = 1, H_1 = 2t, H_n = 2t H_{n-1} - 2(n-1) H_{n-2}  (hermite_kan_layers.py:117-146; base_activation is called as given, :65)."""
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs, none_is_identity=False)
+
+    def _coeffs(self):
+        return 1.0, 2.0, 0.0, [(2.0, 0.0, -2.0 * (k - 1)) for k in range(2, self.degree + 1)]
+
+
+class HermiteKANConv2DLayer(HermiteKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Laguerre
+class LaguerreKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """L_0 = 1, L_1 = 1 + a - t, k L_k = (2k - 1 + a - t) L_{k-1} - (k - 1 + a) L_{k-2}  (laguerre_kan_layers.py)."""
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, alpha, groups=1, padding=0, stride=1,
+                 dilation=1, ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        if alpha <= -1.0:
+            raise ValueError('alpha must be greater than -1 for Laguerre polynomials')
+        self.alpha = alpha
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs)
+
+    def _coeffs(self):
+        a = float(self.alpha)
+        return 1.0, -1.0, 1.0 + a, [(-1.0 / k, (2.0 * k - 1.0 + a) / k, -(k - 1.0 + a) / k) for k in range(2, self.degree + 1)]
+
+
+class LaguerreKANConv2DLayer(LaguerreKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, alpha, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, alpha=alpha, groups=groups, padding=padding, stride=stride,
+                         dilation=dilation, ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Lucas
+class LucasKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """L_0 = 2, L_1 = t, L_n = t L_{n-1} + L_{n-2}  (lucas_kan_layers.py:140-174)."""
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs)
+
+    def _coeffs(self):
+        return 2.0, 1.0, 0.0, [(1.0, 0.0, 1.0) for _ in range(2, self.degree + 1)]
+
+
+class LucasKANConv2DLayer(LucasKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Taylor
+class TaylorKANConvNDLayer(_RecurrenceKANConvNDLayer):
+    """`degree` monomials t^0 .. t^(degree-1)  (taylor_kan_layers.py compute_taylor_basis)."""
+    _min_degree = 1
+    _min_degree_msg = 'degree must be at least 1'
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, **norm_kwargs):
+        super().__init__()
+        self._setup(conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
+                    base_activation, dropout, norm_kwargs)
+
+    def _n_planes(self):
+        return self.degree
+
+    def _coeffs(self):
+        return 1.0, 1.0, 0.0, [(1.0, 0.0, 0.0) for _ in range(2, self.degree)]
+
+
+class TaylorKANConv2DLayer(TaylorKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Jacobi
+class JacobiKANConvNDLayer(_HipLayer):
+    """jacobi_kan_layers.py:55-175: y = act(norm(conv(x, W_base) + conv(P(tanh x), poly_weights[g]))), the polynomial planes
+    concatenated PLANE-major (channel index k*C + c, :136) and the activation applied after the norm (:165)."""
+
+    def __init__(self, conv_class, norm_class, conv_w_fun, input_dim, output_dim, degree, kernel_size, base_activation=nn.GELU,
+                 a: float = 1.0, b: float = 1.0, groups=1, padding=0, stride=1, dilation=1, dropout: float = 0.0, ndim: int = 2,
+                 **norm_kwargs):
+        super().__init__()
+        _need_conv2d(conv_class, ndim)
+        self.input_dim, self.output_dim, self.degree, self.kernel_size = input_dim, output_dim, degree, kernel_size
+        self.padding, self.stride, self.dilation, self.groups = padding, stride, dilation, groups
+        self.base_activation = base_activation() if base_activation is not None else nn.Identity()
+        self.conv_w_fun, self.ndim, self.norm_kwargs, self.a, self.b = conv_w_fun, ndim, norm_kwargs, a, b
+        self.dropout = None
+        if dropout > 0:
+            raise NotImplementedError("JacobiKAN applies dropout to the expanded basis planes (jacobi_kan_layers.py:148-149); "
+                                      "the fused conv stage never materialises them -- use dropout=0")
+        _check_groups(groups, input_dim, output_dim)
+        if degree < 1 or degree > 10:
+            raise NotImplementedError("JacobiKAN on the HIP path needs 1 <= degree <= 10")
+        if not isinstance(kernel_size, int):
+            raise TypeError("JacobiKAN takes an int kernel_size (jacobi_kan_layers.py:108-109,116)")
+        cg, og = input_dim // groups, output_dim // groups
+        self.base_conv = nn.ModuleList([conv_class(cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                        for _ in range(groups)])
+        self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
+        self.poly_weights = nn.Parameter(torch.randn(groups, og, cg * (degree + 1), *([kernel_size] * ndim)))
+        for conv in self.base_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        nn.init.normal_(self.poly_weights, mean=0.0, std=1 / (input_dim * (degree + 1) * kernel_size ** ndim))
+
+    def _coeffs(self) -> Coeffs:
+        a, b = float(self.a), float(self.b)
+        rec = []
+        for i in range(2, self.degree + 1):                      # jacobi_kan_layers.py:127-133
+            th = (2 * i + a + b) * (2 * i + a + b - 1) / (2 * i * (i + a + b))
+            th1 = (2 * i + a + b - 1) * (a * a - b * b) / (2 * i * (i + a + b) * (2 * i + a + b - 2))
+            th2 = (i + a - 1) * (i + b - 1) * (2 * i + a + b) / (i * (i + a + b) * (2 * i + a + b - 2))
+            rec.append((th, th1, -th2))
+        return 1.0, (a + b + 2.0) / 2.0, (a - b) / 2.0, rec
+
+    def conv_spec(self) -> ops.ConvSpec:
+        n = self.degree + 1
+        return self._spec(kind=L.BASIS_POLY, n_basis=n, order=1, act=L.ACT_IDENTITY, p0=0.0, p1=0.0, table=_table(self._coeffs(), n))
+
+    def forward(self, x):
+        G, n = self.groups, self.degree + 1
+        og, cg, k = self.output_dim // G, self.input_dim // G, self.kernel_size
+        # plane-major (k*C + c) -> the kernels' channel-major (c*n + k) order; autograd carries the gradient back
+        ws = [self.poly_weights[g].view(og, n, cg, k, k).transpose(1, 2).reshape(og, cg * n, k, k) for g in range(G)]
+        z = ops.kan_conv(self.conv_spec(), x, None, [m.weight for m in self.base_conv], ws)
+        if _fusable_instnorm(self.layer_norm):
+            gam, bet = self._norm_affine(self.layer_norm)
+            y = ops.instance_norm(z, torch.cat(gam) if gam is not None else None, torch.cat(bet) if bet is not None else None,
+                                  eps=self.layer_norm[0].eps)
+        else:
+            parts = []
+            for g in range(G):
+                zg = z[:, g * og:(g + 1) * og]
+                if isinstance(self.layer_norm[g], nn.LayerNorm):
+                    zg = self.layer_norm[g](zg.reshape(zg.shape[0], -1)).view(zg.shape)
+                else:
+                    zg = self.layer_norm[g](zg)
+                parts.append(zg)
+            y = torch.cat(parts, dim=1)
+        return self.base_activation(y)
+
+
+class JacobiKANConv2DLayer(JacobiKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree=3, base_activation=nn.GELU, a=1.0, b=1.0, groups=1, padding=0,
+                 stride=1, dilation=1, dropout: float = 0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, conv_w_fun=torch.nn.functional.conv2d, input_dim=input_dim,
+                         output_dim=output_dim, degree=degree, kernel_size=kernel_size, base_activation=base_activation, a=a, b=b,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2, dropout=dropout, **norm_kwargs)

@@ -150,6 +150,95 @@ def chebykan_conv2d(x: Tensor, w_poly: Sequence[Tensor], *, degree: int,
     return _per_group(x, groups, one)
 
 
+# --------------------------------------------------------------------------- polynomial families (section 8(f), rank 3)
+def poly_basis(x: Tensor, family: str, degree: int, **kw) -> Tensor:
+    """Basis planes [B, C, n, H, W] of the three-term-recurrence conv-KAN families, each restated from its own file
+    (all evaluate on t = tanh(x)):
+      bessel      bessel_kan_layers.py compute_bessel_basis:        y0 = 1, y1 = t + 1, yn = (2n-1) t y(n-1) + y(n-2)
+      fibonacci   fibonacci_kan_layers.py compute_fibonacci_basis:  F0 = 0, F1 = 1, Fn = t F(n-1) + F(n-2)
+      gegenbauer  gegenbauer_kan_layers.py compute_gegenbauer_basis: C0 = 1, C1 = 2 a t, C(n+1) = (2(n+a) t Cn - (n+2a-1) C(n-1))/(n+1)
+      hermite     hermite_kan_layers.py:117-146:                     H0 = 1, H1 = 2t, Hn = 2t H(n-1) - 2(n-1) H(n-2)
+      laguerre    laguerre_kan_layers.py compute_laguerre_basis:     L0 = 1, L1 = 1 + a - t, Lk = ((2k-1+a-t) L(k-1) - (k-1+a) L(k-2))/k
+      lucas       lucas_kan_layers.py:140-174:                       L0 = 2, L1 = t, Ln = t L(n-1) + L(n-2)
+      taylor      taylor_kan_layers.py compute_taylor_basis:         `degree` planes t^0 .. t^(degree-1)
+      jacobi      jacobi_kan_layers.py:118-136:                      P0 = 1, P1 = ((a-b) + (a+b+2) t)/2, Pi = (th t + th1) P(i-1) - th2 P(i-2)
+    """
+    t = torch.tanh(x)
+    one = torch.ones_like(t)
+    if family == "taylor":
+        planes = [one]
+        for _ in range(1, degree):
+            planes.append(planes[-1] * t if len(planes) > 1 else t)
+        return torch.stack(planes[:degree], dim=2)
+    if family == "bessel":
+        p = [one, t + 1]
+        for i in range(2, degree + 1):
+            p.append((2 * i - 1) * t * p[i - 1] + p[i - 2])
+    elif family == "fibonacci":
+        p = [torch.zeros_like(t), one]
+        for i in range(2, degree + 1):
+            p.append(t * p[i - 1] + p[i - 2])
+    elif family == "gegenbauer":
+        a = kw["alpha_param"]
+        p = [one, 2 * a * t]
+        for n in range(1, degree):
+            p.append((2 * (n + a) * t * p[n] - (n + 2 * a - 1) * p[n - 1]) / (n + 1))
+    elif family == "hermite":
+        p = [one, 2 * t]
+        for i in range(2, degree + 1):
+            p.append(2 * t * p[i - 1] - 2 * (i - 1) * p[i - 2])
+    elif family == "laguerre":
+        a = kw["alpha"]
+        p = [one, (1 + a) - t]
+        for k in range(2, degree + 1):
+            p.append(((2 * (k - 1) + 1 + a - t) * p[k - 1] - (k - 1 + a) * p[k - 2]) / k)
+    elif family == "lucas":
+        p = [2 * one, t]
+        for i in range(2, degree + 1):
+            p.append(t * p[i - 1] + p[i - 2])
+    elif family == "jacobi":
+        a, b = kw["a"], kw["b"]
+        p = [one, ((a - b) + (a + b + 2) * t) / 2]
+        for i in range(2, degree + 1):
+            th = (2 * i + a + b) * (2 * i + a + b - 1) / (2 * i * (i + a + b))
+            th1 = (2 * i + a + b - 1) * (a * a - b * b) / (2 * i * (i + a + b) * (2 * i + a + b - 2))
+            th2 = (i + a - 1) * (i + b - 1) * (2 * i + a + b) / (i * (i + a + b) * (2 * i + a + b - 2))
+            p.append((th * t + th1) * p[i - 1] - th2 * p[i - 2])
+    else:
+        raise ValueError(family)
+    return torch.stack(p[:degree + 1], dim=2)
+
+
+def polykan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_poly: Sequence[Tensor], prelu_a: Sequence[Tensor], *, family: str,
+                   degree: int, act: Optional[Callable[[Tensor], Tensor]], stride=1, padding=0, dilation=1, groups: int = 1,
+                   norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None, **kw) -> Tensor:
+    """PReLU(norm(conv(act(x), W_b) + conv(basis(tanh x), W_p))), poly channel = c*n + k  (e.g. lucas_kan_layers.py:176-193)."""
+    def one(xg, g):
+        a = xg if act is None else act(xg)
+        z = _conv(a, w_base[g], stride, padding, dilation) + _conv(poly_basis(xg, family, degree, **kw).flatten(1, 2), w_poly[g],
+                                                                   stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        return F.prelu(n, prelu_a[g])
+    return _per_group(x, groups, one)
+
+
+def jacobikan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, *, degree: int, a: float, b: float,
+                     act: Optional[Callable[[Tensor], Tensor]], stride=1, padding=0, dilation=1, groups: int = 1,
+                     norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
+    """act(norm(conv(x, W_b) + conv(P(tanh x), poly_weights[g]))), planes concatenated plane-major k*C + c
+    (jacobi_kan_layers.py:136-166)."""
+    def one(xg, g):
+        planes = poly_basis(xg, "jacobi", degree, a=a, b=b).transpose(1, 2).flatten(1, 2)       # [B, n*C, H, W]
+        z = _conv(xg, w_base[g], stride, padding, dilation) + _conv(planes, poly_weights[g], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        return n if act is None else act(n)
+    return _per_group(x, groups, one)
+
+
 # --------------------------------------------------------------------------- whole-model oracle
 VGG11_CFG = [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512]
 

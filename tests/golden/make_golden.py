@@ -30,6 +30,7 @@ sys.path.insert(1, ROOT)
 sys.dont_write_bytecode = True
 
 from layers import KANConv2DLayer, FastKANConv2DLayer, ChebyKANConv2DLayer  # noqa: E402  (reference)
+import layers as REF_LAYERS  # noqa: E402  (reference package)
 from layers import KANLayer as RefKANLayer  # noqa: E402  (reference, layers/kan_layers.py:8-114)
 from oracle import kan_oracle as O  # noqa: E402
 
@@ -107,8 +108,36 @@ CASES = [
 ]
 
 
+# ---- three-term-recurrence polynomial families (section 8(f) rank 3); appended so that the seeds of the cases above stay put
+POLY_FAMILIES = {"bessel": "BesselKANConv2DLayer", "fibonacci": "FibonacciKANConv2DLayer", "gegenbauer": "GegenbauerKANConv2DLayer",
+                 "hermite": "HermiteKANConv2DLayer", "laguerre": "LaguerreKANConv2DLayer", "lucas": "LucasKANConv2DLayer",
+                 "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer"}
+POLY_EXTRA = {"gegenbauer": {"alpha_param": 0.7}, "laguerre": {"alpha": 1.0}, "jacobi": {"a": 1.0, "b": 0.5}}
+POLY_CASES = []
+for _fam in POLY_FAMILIES:
+    POLY_CASES.append(C(_fam, "tiny", 2, 3, 4, 8, 8, degree=3, extra=POLY_EXTRA.get(_fam, {})))
+    POLY_CASES.append(C(_fam, "deg5g2", 2, 4, 6, 7, 5, groups=2, degree=5, act="silu", xs=1.5, extra=POLY_EXTRA.get(_fam, {})))
+POLY_CASES += [
+    C("lucas", "stride2_affine", 2, 4, 6, 9, 9, s=2, degree=4, norm_kwargs={"affine": True}),
+    C("hermite", "x3_k5", 2, 3, 4, 9, 9, k=5, p=2, degree=3, xs=3.0),
+    C("taylor", "deg1", 2, 3, 4, 6, 6, degree=1),
+    C("bessel", "deg0_noact", 2, 3, 4, 6, 6, degree=0, act="none"),
+    C("laguerre", "batchnorm", 3, 3, 4, 8, 8, degree=3, norm="bn", extra={"alpha": 0.0}),
+    C("jacobi", "a0b0_wide", 3, 12, 20, 6, 6, degree=4, act="silu", extra={"a": 0.0, "b": 0.0}),
+    C("gegenbauer", "wide", 3, 20, 40, 6, 6, degree=6, act="silu", extra={"alpha_param": 0.0}),
+]
+
+
 def build_ref(c):
     kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
+    if c["kind"] in POLY_FAMILIES:
+        kw.update(c.get("norm_kwargs", {}))
+        kw.update(c.get("extra", {}))
+        if "norm" in c:
+            kw["norm_layer"] = NORMS[c["norm"]]
+        if "act" in c:
+            kw["base_activation"] = ACTS[c["act"]]
+        return getattr(REF_LAYERS, POLY_FAMILIES[c["kind"]])(c["C"], c["O"], degree=c["degree"], **kw)
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:
         kw["norm_layer"] = NORMS[c["norm"]]
@@ -153,6 +182,13 @@ def oracle_forward(c, layer, x, pre):
         return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)],
                                 [sd[f"spline_conv.{g}.weight"] for g in range(G)],
                                 centres=centres, denom=denom, act=act, norm=norms, **geo)
+    if c["kind"] == "jacobi":
+        return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
+                                  a=layer.a, b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] in POLY_FAMILIES:
+        return O.polykan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"poly_conv.{g}.weight"] for g in range(G)],
+                                [sd[f"prelus.{g}.weight"] for g in range(G)], family=c["kind"], degree=layer.degree,
+                                act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **c.get("extra", {}), **geo)
     return O.chebykan_conv2d(x, [sd[f"poly_conv.{g}.weight"] for g in range(G)], degree=layer.degree,
                              norm=norms, pre_norm_out=pre, **geo)
 
@@ -172,11 +208,14 @@ def run_case(idx, c):
             elif p.dim() == 4:
                 fan_in = p.shape[1] * p.shape[2] * p.shape[3]
                 det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
+            elif p.dim() == 5:                                  # JacobiKAN poly_weights [G, O/G, C/G*(deg+1), k, k]
+                fan_in = p.shape[2] * p.shape[3] * p.shape[4]
+                det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
     x = mk_input((c["B"], c["C"], c["H"], c["W"]), idx, c["xscale"]).requires_grad_(True)
 
     pre_ref = []
     hooks = []
-    if c["kind"] in ("bspline", "cheby"):
+    if c["kind"] in ("bspline", "cheby") or c["kind"] in POLY_FAMILIES:
         for g in range(c["groups"]):
             hooks.append(layer.layer_norm[g].register_forward_pre_hook(lambda m, a: pre_ref.append(a[0].detach().clone())))
     y = layer(x)
@@ -321,6 +360,12 @@ def run_mlp_case(idx, c):
     return worst, os.path.getsize(fn)
 
 
+def poly_cases():
+    for i, c in enumerate(POLY_CASES):
+        worst, sz = run_case(len(CASES) + i, c)
+        print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 def mlp_cases():
     for i, c in enumerate(MLP_CASES):
         worst, sz = run_mlp_case(i, c)
@@ -383,6 +428,8 @@ def run_model(name, model, x, t):
 def main():
     if "--mlp-only" in sys.argv:                    # regenerate just the MLP KANLayer fixtures
         return mlp_cases()
+    if "--poly-only" in sys.argv:                   # regenerate just the polynomial-family fixtures
+        return poly_cases()
     total = 0
     for i, c in enumerate(CASES):
         worst, sz = run_case(i, c)
@@ -390,6 +437,7 @@ def main():
         print(f"{c['kind']:8s} {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
     basis_probes()
     mlp_cases()
+    poly_cases()
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)

@@ -13,11 +13,22 @@ DEFAULT_ACT = {"bspline": "gelu", "rbf": "silu"}
 TOL_Y, TOL_DX, TOL_DW = 1e-5, 1e-5, 5e-5
 
 
+POLY = {"bessel": "BesselKANConv2DLayer", "fibonacci": "FibonacciKANConv2DLayer", "gegenbauer": "GegenbauerKANConv2DLayer",
+        "hermite": "HermiteKANConv2DLayer", "laguerre": "LaguerreKANConv2DLayer", "lucas": "LucasKANConv2DLayer",
+        "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer"}
+
+
 def layer_kwargs(c):
     kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:
         kw["norm_layer"] = NORMS[c["norm"]]
+    if c["kind"] in POLY:
+        kw.update(c.get("extra", {}))
+        kw["degree"] = c["degree"]
+        if "act" in c:
+            kw["base_activation"] = ACTS[c["act"]]
+        return kw
     if c["kind"] == "bspline":
         for key in ("grid_size", "spline_order", "grid_range"):
             if key in c:
@@ -35,6 +46,8 @@ def layer_kwargs(c):
 
 def build_layer(c):
     import convkan_amd as K
+    if c["kind"] in POLY:
+        return getattr(K, POLY[c["kind"]])(c["C"], c["O"], **layer_kwargs(c))
     cls = {"bspline": K.KANConv2DLayer, "rbf": K.FastKANConv2DLayer, "cheby": K.ChebyKANConv2DLayer}[c["kind"]]
     return cls(c["C"], c["O"], **layer_kwargs(c))
 
@@ -60,5 +73,12 @@ def oracle_forward(c, layer, x, pre=None):
         centres, denom = O.rbf_grid(layer.grid_size, layer.grid_range)
         return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"spline_conv.{g}.weight"] for g in range(G)],
                                 centres=centres.to(x.device), denom=denom, act=ACT_FN[c.get("act", "silu")], norm=norms, **geo)
+    if c["kind"] == "jacobi":
+        return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree, a=layer.a,
+                                  b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] in POLY:
+        return O.polykan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"poly_conv.{g}.weight"] for g in range(G)],
+                                [sd[f"prelus.{g}.weight"] for g in range(G)], family=c["kind"], degree=layer.degree,
+                                act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **c.get("extra", {}), **geo)
     return O.chebykan_conv2d(x, [sd[f"poly_conv.{g}.weight"] for g in range(G)], degree=layer.degree, norm=norms,
                              pre_norm_out=pre, **geo)

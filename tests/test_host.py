@@ -116,9 +116,46 @@ def test_constructor_surface():
             cls(4, 3, 3, groups=2)
 
 
+def test_polynomial_family_surface():
+    """State-dict keys, attributes and validation messages of the recurrence families (e.g. lucas_kan_layers.py:76-139)."""
+    for cls in (K.BesselKANConv2DLayer, K.FibonacciKANConv2DLayer, K.HermiteKANConv2DLayer, K.LucasKANConv2DLayer, K.TaylorKANConv2DLayer):
+        m = cls(4, 6, 3, degree=3, groups=2, padding=1)
+        n = 3 if cls is K.TaylorKANConv2DLayer else 4
+        assert list(m.state_dict()) == ["base_conv.0.weight", "base_conv.1.weight", "poly_conv.0.weight", "poly_conv.1.weight",
+                                        "prelus.0.weight", "prelus.1.weight"]
+        assert m.poly_conv[0].weight.shape == (3, 2 * n, 3, 3) and m.poly_input_dim_group == 2 * n
+        with pytest.raises(ValueError, match="positive"):
+            cls(4, 6, 3, degree=3, groups=0)
+    with pytest.raises(ValueError, match="at least 1"):
+        K.FibonacciKANConv2DLayer(3, 4, 3, degree=0)
+    with pytest.raises(ValueError, match="at least 1"):
+        K.TaylorKANConv2DLayer(3, 4, 3, degree=0)
+    with pytest.raises(ValueError, match="non-negative"):
+        K.LucasKANConv2DLayer(3, 4, 3, degree=-1)
+    with pytest.raises(ValueError, match="greater than -0.5"):
+        K.GegenbauerKANConv2DLayer(3, 4, 3, degree=2, alpha_param=-0.5)
+    with pytest.raises(ValueError, match="greater than -1"):
+        K.LaguerreKANConv2DLayer(3, 4, 3, degree=2, alpha=-1.0)
+    j = K.JacobiKANConv2DLayer(4, 6, 3, degree=3, groups=2)
+    assert list(j.state_dict()) == ["poly_weights", "base_conv.0.weight", "base_conv.1.weight"] and j.poly_weights.shape == (2, 3, 8, 3, 3)
+    spec = K.LaguerreKANConv2DLayer(3, 4, 3, degree=3, alpha=1.0).conv_spec()
+    assert spec.kind == L.BASIS_POLY and spec.n_basis == 4 and spec.order == 1
+    assert spec.table[:3] == (1.0, -1.0, 2.0) and spec.table[3:6] == (-0.5, 2.0, -1.0)      # L_2 = ((4 - t) L_1 - 2 L_0) / 2
+
+
 def test_factory_signatures_and_same_padding():
     F = K.CONV_KAN_FACTORY
-    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "conv"}
+    poly = {"BesselKAN", "FibonacciKAN", "GegenbauerKAN", "HermiteKAN", "JacobiKAN", "LaguerreKAN", "LucasKAN", "TaylorKAN"}
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "conv"} | poly
+    for name in poly:                                            # kan_conv.py:354-724: shared leading arguments and defaults
+        sig = inspect.signature(F[name])
+        assert list(sig.parameters)[:7] == ["in_planes", "out_planes", "kernel_size", "groups", "stride", "dilation", "padding"]
+        assert sig.parameters["degree"].default == 3 and sig.parameters["base_activation"].default is nn.GELU
+        layer = F[name](4, 6, 3, dilation=2)                     # dilation only enters the 'same' padding, as in the reference
+        assert layer.padding == 2 and layer.dilation == 1 and layer.degree == 3
+    assert inspect.signature(F["GegenbauerKAN"]).parameters["alpha_param"].default == 0.0
+    assert inspect.signature(F["LaguerreKAN"]).parameters["alpha"].default == 1.0
+    assert (F["JacobiKAN"](4, 6, 3).a, F["JacobiKAN"](4, 6, 3, b=0.5).b) == (1.0, 0.5)
     sig = inspect.signature(F["KAN"])
     assert list(sig.parameters)[:3] == ["in_planes", "out_planes", "kernel_size"]
     assert sig.parameters["grid_size"].default == 5 and sig.parameters["base_activation"].default is nn.GELU

@@ -28,6 +28,9 @@ class _Params(nn.Module):
             if n in ("base_conv", "spline_conv", "poly_conv", "prelus"):
                 lst = nn.ParameterList([nn.Parameter(torch.from_numpy(d[f"sd.{n}.{g}.weight"])) for g in range(G)])
                 setattr(self, n + "_p", lst)
+        if "sd.poly_weights" in d:                                # JacobiKAN: one [G, O/G, C/G*(deg+1), k, k] parameter
+            self.poly_weights = nn.Parameter(torch.from_numpy(d["sd.poly_weights"]))
+            self.a, self.b = c["extra"]["a"], c["extra"]["b"]
         norm_cls = NORMS[c.get("norm", "in")]
         nch = (c["C"] if c["kind"] == "rbf" else c["O"]) // G
         kw = {k: v for k, v in c.get("norm_kwargs", {}).items()}

@@ -160,6 +160,21 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
                 v[p] = DERIV ? e * (-2.0f * u) / dn : e;
             }
         }
+    } else if (KIND == KAN_BASIS_FOURIER) {
+        // fourier_kan_layers.py:163-187: planes cos(k x), k = 1..G, then sin(k x), k = 1..G (nb = 2G).  The argument is
+        // formed as fl(k * x) exactly as the reference does, so large |x| rounds the same way.
+        const int G = bs.nb >> 1;
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p) {
+            const int j = p - hb;
+            if (j >= 0 && j < bs.nb) {
+                const bool is_cos = j < G;
+                const float k = (float)((is_cos ? j : j - G) + 1);
+                float sn, cs;
+                sincosf(k * xb, &sn, &cs);
+                v[p] = is_cos ? (DERIV ? -k * sn : cs) : (DERIV ? k * cs : sn);
+            }
+        }
     } else if (KIND == KAN_BASIS_POLY) {
         // Three-term-recurrence families (bessel / fibonacci / gegenbauer / hermite / laguerre / lucas / taylor / jacobi
         // _kan_layers.py, compute_*_basis): on t = tanh(x) (order = 1) or t = x (order = 0),

@@ -1067,7 +1067,8 @@ int check(const KanGeom* g, const KanBasis* b) {
         return fail("activation tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     if (g->x_bstride < (long long)ngroups(g) * g->C * g->H * g->W || g->y_bstride < (long long)ngroups(g) * g->O * g->Ho * g->Wo)
         return fail("batch stride smaller than groups * channels * plane");
-    if (b->kind < 0 || b->kind > KAN_BASIS_POLY) return fail("unknown basis kind");
+    if (b->kind < 0 || b->kind > KAN_BASIS_FOURIER) return fail("unknown basis kind");
+    if (b->kind == KAN_BASIS_FOURIER && (b->n_basis & 1)) return fail("Fourier basis needs an even plane count (cos and sin per frequency)");
     if (b->kind == KAN_BASIS_POLY && (b->n_basis > 11 || b->order < 0 || b->order > 1)) return fail("bad recurrence-basis parameters");
     if (b->act < KAN_ACT_NONE || b->act > KAN_ACT_GELU_TANH) return fail("unknown activation");
     int P = b->n_basis + (b->act != KAN_ACT_NONE);
@@ -1476,6 +1477,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_FWD_KIND(KAN_BASIS_POLY);
+    else if (b->kind == KAN_BASIS_FOURIER) KAN_FWD_KIND(KAN_BASIS_FOURIER);
     else KAN_FWD_KIND(KAN_BASIS_CHEBY);
 #undef KAN_FWD_FAST
 #undef KAN_FWD_KIND
@@ -1513,6 +1515,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
+    else if (b->kind == KAN_BASIS_FOURIER) KAN_BD(KAN_BASIS_FOURIER);
     else KAN_BD(KAN_BASIS_CHEBY);
 #undef KAN_BD
     return launch_ok("conv_bwd_data");
@@ -1546,6 +1549,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BW_KIND(KAN_BASIS_POLY);
+    else if (b->kind == KAN_BASIS_FOURIER) KAN_BW_KIND(KAN_BASIS_FOURIER);
     else KAN_BW_KIND(KAN_BASIS_CHEBY);
 #undef KAN_BW_FAST
 #undef KAN_BW_KIND

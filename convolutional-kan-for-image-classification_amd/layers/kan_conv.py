@@ -3,16 +3,16 @@
 ``CONV_KAN_FACTORY[name](in_planes, out_planes, kernel_size=..., ...)`` is the drop-in boundary the
 reference's models use (models/kan_vgg.py:73-101, models/kan_alexnet.py:54-69).  Registered: the three
 basis families of the hot path, the eight three-term-recurrence polynomial families of SURVEY.md
-section 8(f) rank 3 (Bessel, Fibonacci, Gegenbauer, Hermite, Jacobi, Laguerre, Lucas, Taylor) and the
+section 8(f) rank 3 (Bessel, Fibonacci, Gegenbauer, Hermite, Jacobi, Laguerre, Lucas, Taylor), FourierKAN and the
 plain ``conv`` helper.  Not built: Legendre (batch-global min/max normalisation), GRAM, Wav, Bernstein,
-Fourier, ReLU-KAN.
+ReLU-KAN.
 """
 from typing import Callable, List, Optional, Tuple, Union
 
 import torch.nn as nn
 
 from .conv_layers import ChebyKANConv2DLayer, FastKANConv2DLayer, KANConv2DLayer
-from .poly_layers import (BesselKANConv2DLayer, FibonacciKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
+from .poly_layers import (BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
                           JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 
 _IntOrPair = Union[int, Tuple[int, int]]
@@ -118,6 +118,18 @@ def fibonaccikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, 
                                    norm_layer=norm_layer, **norm_kwargs)
 
 
+def fourierkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                    dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                    grid_size: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                    norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> FourierKANConv2DLayer:
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return FourierKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, grid_size=grid_size, groups=groups,
+                                 padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
+                                 norm_layer=norm_layer, **norm_kwargs)
+
+
 def gegenbauerkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
                        dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
                        degree: int = 3, alpha_param: float = 0.0, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
@@ -197,6 +209,7 @@ CONV_KAN_FACTORY = {
     "ChebyKAN": chebykan_conv,
     "BesselKAN": besselkan_conv,
     "FibonacciKAN": fibonaccikan_conv,
+    "FourierKAN": fourierkan_conv,
     "GegenbauerKAN": gegenbauerkan_conv,
     "HermiteKAN": hermitekan_conv,
     "JacobiKAN": jacobikan_conv,

@@ -9,6 +9,7 @@
   lucas_kan_layers.py:40-218       LucasKANConvNDLayer/2D       LucasKANConvNDLayer / LucasKANConv2DLayer
   taylor_kan_layers.py:40-195      TaylorKANConvNDLayer/2D      TaylorKANConvNDLayer / TaylorKANConv2DLayer
   jacobi_kan_layers.py:55-199      JacobiKANConvNDLayer/2D      JacobiKANConvNDLayer / JacobiKANConv2DLayer
+  fourier_kan_layers.py:63-231     FourierKANConvNDLayer/2D     FourierKANConvNDLayer / FourierKANConv2DLayer  (own basis kind)
 
 The first seven share one shape (e.g. lucas_kan_layers.py:176-199):
     y = Dropout(PReLU(norm(conv(act(x), W_base) + conv(basis(tanh x), W_poly))))
@@ -265,6 +266,68 @@ class TaylorKANConv2DLayer(TaylorKANConvNDLayer):
                  base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
         super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Fourier
+class FourierKANConvNDLayer(_HipLayer):
+    """fourier_kan_layers.py:63-212: y = Dropout(PReLU(norm(conv(act(x), W_base) + conv([cos(kx)]_k ++ [sin(kx)]_k, W_fourier)))),
+    k = 1..grid_size, channel index c*2G + (k-1) for the cosines and c*2G + G + (k-1) for the sines (:184-186)."""
+
+    def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, grid_size, groups=1, padding=0, stride=1, dilation=1,
+                 ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, smooth_initialization: bool = False, **norm_kwargs):
+        super().__init__()
+        _need_conv2d(conv_class, ndim)
+        _check_groups(groups, input_dim, output_dim)
+        if grid_size < 1:
+            raise ValueError('grid_size must be at least 1')
+        if 2 * grid_size + 1 > L.KAN_MAX_PLANES:
+            raise NotImplementedError(f"the HIP conv stage holds at most {L.KAN_MAX_PLANES} planes per channel (grid_size <= 7)")
+        self.input_dim, self.output_dim, self.kernel_size, self.grid_size = input_dim, output_dim, kernel_size, grid_size
+        self.groups, self.padding, self.stride, self.dilation, self.ndim = groups, padding, stride, dilation, ndim
+        self.base_activation = base_activation() if base_activation is not None else nn.Identity()
+        self.norm_kwargs = norm_kwargs
+        self.input_dim_group, self.output_dim_group = input_dim // groups, output_dim // groups
+        self.fourier_input_dim_group = self.input_dim_group * (2 * grid_size)
+        cg, og = self.input_dim_group, self.output_dim_group
+        self.base_conv = nn.ModuleList([conv_class(cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                        for _ in range(groups)])
+        self.fourier_conv = nn.ModuleList([conv_class(self.fourier_input_dim_group, og, kernel_size, stride, padding, dilation, groups=1,
+                                                      bias=False) for _ in range(groups)])
+        self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
+        self.prelus = nn.ModuleList([nn.PReLU() for _ in range(groups)])
+        self.dropout = _dropout2d(dropout)
+        for conv in self.base_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        for conv in self.fourier_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        self._act_code = _act_code(self.base_activation)
+
+    def conv_spec(self) -> ops.ConvSpec:
+        return self._spec(kind=L.BASIS_FOURIER, n_basis=2 * self.grid_size, order=0, act=self._act_code, p0=0.0, p1=0.0, table=())
+
+    def forward(self, x):
+        spec = self.conv_spec()
+        wb = [m.weight for m in self.base_conv]
+        ws = [m.weight for m in self.fourier_conv]
+        prelus = [m.weight for m in self.prelus]
+        if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
+            gam, bet = self._norm_affine(self.layer_norm)
+            y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
+        else:
+            z = ops.kan_conv(spec, x, None, wb, ws)
+            og = self.output_dim_group
+            y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
+        if self.dropout is not None:
+            y = self.dropout(y)
+        return y
+
+
+class FourierKANConv2DLayer(FourierKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, grid_size, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, grid_size=grid_size, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 

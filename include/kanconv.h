@@ -33,7 +33,7 @@ extern "C" {
 #define KAN_MAX_TABLE  32   /* knots (B-spline) or centres (RBF) */
 
 /* basis families */
-enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3 };
+enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3, KAN_BASIS_FOURIER = 4 };
 /* base-branch activations; KAN_ACT_NONE = layer has no base branch (ChebyKAN) */
 enum { KAN_ACT_NONE = -1, KAN_ACT_IDENTITY = 0, KAN_ACT_GELU = 1, KAN_ACT_SILU = 2, KAN_ACT_RELU = 3,
        KAN_ACT_TANH = 4, KAN_ACT_SIGMOID = 5, KAN_ACT_GELU_TANH = 6 };
@@ -61,6 +61,8 @@ typedef struct KanGeom {
  *              layers/<family>_kan_layers.py compute_*_basis).  n_basis planes T_0..T_{n-1} of t = tanh(x) (order = 1)
  *              or t = x (order = 0):  T_0 = table[0], T_1 = table[1]*t + table[2],
  *              T_k = (table[3k-3]*t + table[3k-2]) * T_{k-1} + table[3k-1] * T_{k-2} for k >= 2;  n_basis <= 11
+ *   Fourier  : n_basis = 2*grid_size planes cos(k x), k = 1..grid_size, then sin(k x)
+ *              (layers/fourier_kan_layers.py:163-187)
  * `act` is the base-branch activation (KAN_ACT_NONE: no base branch, no base weight).
  * Planes per channel P = n_basis + (act != KAN_ACT_NONE); P <= KAN_MAX_PLANES. */
 typedef struct KanBasis {

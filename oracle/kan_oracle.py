@@ -239,6 +239,28 @@ def jacobikan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, 
     return _per_group(x, groups, one)
 
 
+def fourier_basis(x: Tensor, grid_size: int) -> Tensor:
+    """[B, C, 2G, H, W]: cos(k x), k = 1..G, then sin(k x) (fourier_kan_layers.py:163-187)."""
+    k = torch.arange(1, grid_size + 1, device=x.device, dtype=x.dtype).view(1, 1, grid_size, *([1] * (x.dim() - 2)))
+    kx = k * x.unsqueeze(2)
+    return torch.cat((torch.cos(kx), torch.sin(kx)), dim=2)
+
+
+def fourierkan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_fourier: Sequence[Tensor], prelu_a: Sequence[Tensor], *, grid_size: int,
+                      act: Optional[Callable[[Tensor], Tensor]], stride=1, padding=0, dilation=1, groups: int = 1,
+                      norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
+    """PReLU(norm(conv(act(x), W_b) + conv(fourier(x), W_f)))  (fourier_kan_layers.py:189-205)."""
+    def one(xg, g):
+        a = xg if act is None else act(xg)
+        z = _conv(a, w_base[g], stride, padding, dilation) + _conv(fourier_basis(xg, grid_size).flatten(1, 2), w_fourier[g],
+                                                                   stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        return F.prelu(n, prelu_a[g])
+    return _per_group(x, groups, one)
+
+
 # --------------------------------------------------------------------------- whole-model oracle
 VGG11_CFG = [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512]
 

@@ -111,10 +111,10 @@ CASES = [
 # ---- three-term-recurrence polynomial families (section 8(f) rank 3); appended so that the seeds of the cases above stay put
 POLY_FAMILIES = {"bessel": "BesselKANConv2DLayer", "fibonacci": "FibonacciKANConv2DLayer", "gegenbauer": "GegenbauerKANConv2DLayer",
                  "hermite": "HermiteKANConv2DLayer", "laguerre": "LaguerreKANConv2DLayer", "lucas": "LucasKANConv2DLayer",
-                 "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer"}
+                 "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer", "fourier": "FourierKANConv2DLayer"}
 POLY_EXTRA = {"gegenbauer": {"alpha_param": 0.7}, "laguerre": {"alpha": 1.0}, "jacobi": {"a": 1.0, "b": 0.5}}
 POLY_CASES = []
-for _fam in POLY_FAMILIES:
+for _fam in [f for f in POLY_FAMILIES if f != "fourier"]:
     POLY_CASES.append(C(_fam, "tiny", 2, 3, 4, 8, 8, degree=3, extra=POLY_EXTRA.get(_fam, {})))
     POLY_CASES.append(C(_fam, "deg5g2", 2, 4, 6, 7, 5, groups=2, degree=5, act="silu", xs=1.5, extra=POLY_EXTRA.get(_fam, {})))
 POLY_CASES += [
@@ -125,6 +125,11 @@ POLY_CASES += [
     C("laguerre", "batchnorm", 3, 3, 4, 8, 8, degree=3, norm="bn", extra={"alpha": 0.0}),
     C("jacobi", "a0b0_wide", 3, 12, 20, 6, 6, degree=4, act="silu", extra={"a": 0.0, "b": 0.0}),
     C("gegenbauer", "wide", 3, 20, 40, 6, 6, degree=6, act="silu", extra={"alpha_param": 0.0}),
+    # FourierKAN (fourier_kan_layers.py): `degree` carries grid_size here
+    C("fourier", "tiny", 2, 3, 4, 8, 8, degree=3),
+    C("fourier", "g5g2", 2, 4, 6, 7, 5, groups=2, degree=5, act="silu", xs=1.5),
+    C("fourier", "g7_x10", 2, 3, 4, 8, 8, degree=7, xs=10.0),                  # large arguments: fl(k*x) rounding as the reference
+    C("fourier", "g1_affine_s2", 2, 4, 6, 9, 9, s=2, degree=1, norm_kwargs={"affine": True}),
 ]
 
 
@@ -137,6 +142,8 @@ def build_ref(c):
             kw["norm_layer"] = NORMS[c["norm"]]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
+        if c["kind"] == "fourier":
+            return REF_LAYERS.FourierKANConv2DLayer(c["C"], c["O"], grid_size=c["degree"], **kw)
         return getattr(REF_LAYERS, POLY_FAMILIES[c["kind"]])(c["C"], c["O"], degree=c["degree"], **kw)
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:
@@ -185,6 +192,10 @@ def oracle_forward(c, layer, x, pre):
     if c["kind"] == "jacobi":
         return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
                                   a=layer.a, b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "fourier":
+        return O.fourierkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"fourier_conv.{g}.weight"] for g in range(G)],
+                                   [sd[f"prelus.{g}.weight"] for g in range(G)], grid_size=layer.grid_size,
+                                   act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
     if c["kind"] in POLY_FAMILIES:
         return O.polykan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"poly_conv.{g}.weight"] for g in range(G)],
                                 [sd[f"prelus.{g}.weight"] for g in range(G)], family=c["kind"], degree=layer.degree,
@@ -361,7 +372,10 @@ def run_mlp_case(idx, c):
 
 
 def poly_cases():
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--kind=")]
     for i, c in enumerate(POLY_CASES):
+        if only and c["kind"] not in only:
+            continue
         worst, sz = run_case(len(CASES) + i, c)
         print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 

@@ -15,7 +15,7 @@ TOL_Y, TOL_DX, TOL_DW = 1e-5, 1e-5, 5e-5
 
 POLY = {"bessel": "BesselKANConv2DLayer", "fibonacci": "FibonacciKANConv2DLayer", "gegenbauer": "GegenbauerKANConv2DLayer",
         "hermite": "HermiteKANConv2DLayer", "laguerre": "LaguerreKANConv2DLayer", "lucas": "LucasKANConv2DLayer",
-        "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer"}
+        "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer", "fourier": "FourierKANConv2DLayer"}
 
 
 def layer_kwargs(c):
@@ -25,7 +25,7 @@ def layer_kwargs(c):
         kw["norm_layer"] = NORMS[c["norm"]]
     if c["kind"] in POLY:
         kw.update(c.get("extra", {}))
-        kw["degree"] = c["degree"]
+        kw["grid_size" if c["kind"] == "fourier" else "degree"] = c["degree"]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
         return kw
@@ -76,6 +76,10 @@ def oracle_forward(c, layer, x, pre=None):
     if c["kind"] == "jacobi":
         return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree, a=layer.a,
                                   b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "fourier":
+        return O.fourierkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"fourier_conv.{g}.weight"] for g in range(G)],
+                                   [sd[f"prelus.{g}.weight"] for g in range(G)], grid_size=layer.grid_size,
+                                   act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
     if c["kind"] in POLY:
         return O.polykan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"poly_conv.{g}.weight"] for g in range(G)],
                                 [sd[f"prelus.{g}.weight"] for g in range(G)], family=c["kind"], degree=layer.degree,

@@ -146,7 +146,11 @@ def test_polynomial_family_surface():
 def test_factory_signatures_and_same_padding():
     F = K.CONV_KAN_FACTORY
     poly = {"BesselKAN", "FibonacciKAN", "GegenbauerKAN", "HermiteKAN", "JacobiKAN", "LaguerreKAN", "LucasKAN", "TaylorKAN"}
-    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "conv"} | poly
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "conv"} | poly
+    assert inspect.signature(F["FourierKAN"]).parameters["grid_size"].default == 3
+    fl = F["FourierKAN"](4, 6, 3, groups=2)
+    assert list(fl.state_dict())[:4] == ["base_conv.0.weight", "base_conv.1.weight", "fourier_conv.0.weight", "fourier_conv.1.weight"]
+    assert fl.fourier_conv[0].weight.shape == (3, 2 * 6, 3, 3) and fl.fourier_input_dim_group == 12
     for name in poly:                                            # kan_conv.py:354-724: shared leading arguments and defaults
         sig = inspect.signature(F[name])
         assert list(sig.parameters)[:7] == ["in_planes", "out_planes", "kernel_size", "groups", "stride", "dilation", "padding"]

@@ -19,13 +19,13 @@ class _Params(nn.Module):
         super().__init__()
         c = d["cfg"]
         G = c["groups"]
-        self.grid_size = c.get("grid_size", 5 if c["kind"] == "bspline" else 8)
+        self.grid_size = c.get("grid_size", 5 if c["kind"] == "bspline" else 8) if c["kind"] != "fourier" else c["degree"]
         self.spline_order = c.get("spline_order", 3)
         self.grid_range = c.get("grid_range", [-1, 1] if c["kind"] == "bspline" else [-2, 2])
         self.degree = c.get("degree", 3)
         names = sorted({k[3:].split(".")[0] for k in d if k.startswith("sd.")})
         for n in names:
-            if n in ("base_conv", "spline_conv", "poly_conv", "prelus"):
+            if n in ("base_conv", "spline_conv", "poly_conv", "fourier_conv", "prelus"):
                 lst = nn.ParameterList([nn.Parameter(torch.from_numpy(d[f"sd.{n}.{g}.weight"])) for g in range(G)])
                 setattr(self, n + "_p", lst)
         if "sd.poly_weights" in d:                                # JacobiKAN: one [G, O/G, C/G*(deg+1), k, k] parameter

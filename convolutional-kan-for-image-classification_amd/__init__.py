@@ -11,5 +11,5 @@ from .layers import (CONV_KAN_FACTORY, KANConv2DLayer, KANConvNDLayer, FastKANCo
 from .build import build_library                                          # noqa: F401
 
 __version__ = "0.1.0"
-from .layers.poly_layers import (FourierKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,   # noqa: F401,E402
+from .layers.poly_layers import (LegendreKANConv2DLayer, BersnsteinKANConv2DLayer, FourierKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,   # noqa: F401,E402
                                  JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
         pbase = g.pix_major ? (hi0 * g.W + wi0) * g.B + b : b * (int)g.xbs + hi0 * g.W + wi0;
     }
     const int estride = g.pix_major ? g.B : 1;               // element stride of the (c,hi,wi) index
-    const bool same_in = (KIND != KAN_BASIS_RBF) || (x == xn);     // only FastKAN evaluates its basis on a second tensor
+    const bool same_in = (KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);     // FastKAN / LegendreKAN evaluate their basis on a second tensor
     const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes);
     const int wv = wave;
     const unsigned wlane = (unsigned)((lane / (TO / 4)) * Opad + (lane % (TO / 4)) * 4) * 4u;   // this lane inside a 1-KiB weight block
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
         }
         sItem[i] = v;
     }
-    const bool same_in = (KIND != KAN_BASIS_RBF) || (x == xn);
+    const bool same_in = (KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);
     __syncthreads();
 
     float xa[UPF], xb[UPF], zr[ZL]; unsigned inb_mask = 0;
@@ -1441,7 +1441,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     if (!x || !xn || !wp || !z) return fail("null tensor pointer");
     FwdCfg c = fwd_cfg(g, pl);
     DevGeom dg = dev_geom(g);
-    dg.pix_major = (x_pm && want_pix_major(g, b, PM_FWD)) ? 1 : 0;
+    dg.pix_major = (x_pm && x == xn && want_pix_major(g, b, PM_FWD)) ? 1 : 0;      // (one copy serves both inputs only when they are the same)
     if (dg.pix_major) { x = x_pm; xn = x_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;
@@ -1528,7 +1528,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     if (!dz || !x || !xn || !dwp) return fail("null tensor pointer");
     BwCfg c = bw_cfg(g, pl);
     DevGeom dg = dev_geom(g);
-    dg.pix_major = (x_pm && dz_pm && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
+    dg.pix_major = (x_pm && dz_pm && x == xn && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     if (dg.pix_major) { x = x_pm; xn = x_pm; dz = dz_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;

@@ -4,15 +4,15 @@
 reference's models use (models/kan_vgg.py:73-101, models/kan_alexnet.py:54-69).  Registered: the three
 basis families of the hot path, the eight three-term-recurrence polynomial families of SURVEY.md
 section 8(f) rank 3 (Bessel, Fibonacci, Gegenbauer, Hermite, Jacobi, Laguerre, Lucas, Taylor), FourierKAN and the
-plain ``conv`` helper.  Not built: Legendre (batch-global min/max normalisation), GRAM, Wav, Bernstein,
-ReLU-KAN.
+plain ``conv`` helper, plus LegendreKAN and BersnsteinKAN.  Not built: GRAM, Wav, ReLU-KAN (learnable parameters
+inside the basis itself).
 """
 from typing import Callable, List, Optional, Tuple, Union
 
 import torch.nn as nn
 
 from .conv_layers import ChebyKANConv2DLayer, FastKANConv2DLayer, KANConv2DLayer
-from .poly_layers import (BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
+from .poly_layers import (BersnsteinKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, LegendreKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
                           JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 
 _IntOrPair = Union[int, Tuple[int, int]]
@@ -94,6 +94,31 @@ def conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int =
 # ---- three-term-recurrence polynomial families.  As in the reference (kan_conv.py:354-724) `dilation` only enters the
 # 'same' padding and is NOT forwarded to the layer, and `l1_decay` travels in **norm_kwargs where the signature filter
 # drops it (Taylor: not forwarded at all).
+def legendrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, degree: int = 3, groups: int = 1, stride: _IntOrPair = 1,
+                     dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, dropout: float = 0.0,
+                     norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, l1_decay: float = 0.0,
+                     **norm_kwargs) -> LegendreKANConv2DLayer:
+    """kan_conv.py:120-155 (this one does forward `dilation`)."""
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return LegendreKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
+                                  padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer, **norm_kwargs)
+
+
+def bersnsteinkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                       dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                       degree: int = 3, norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d,
+                       **norm_kwargs) -> BersnsteinKANConv2DLayer:
+    """kan_conv.py:319-351 (forwards `dilation`; `l1_decay` rides in **norm_kwargs and is filtered out)."""
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return BersnsteinKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+                                    stride=stride, padding=padding, dilation=dilation, dropout=dropout, l1_decay=l1_decay,
+                                    norm_layer=norm_layer, **norm_kwargs)
+
+
 def besselkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
                    dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
                    degree: int = 3, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
@@ -207,6 +232,8 @@ CONV_KAN_FACTORY = {
     "KAN": kan_conv,
     "FastKAN": fastkan_conv,
     "ChebyKAN": chebykan_conv,
+    "LegendreKAN": legendrekan_conv,
+    "BersnsteinKAN": bersnsteinkan_conv,
     "BesselKAN": besselkan_conv,
     "FibonacciKAN": fibonaccikan_conv,
     "FourierKAN": fourierkan_conv,

@@ -10,6 +10,8 @@
   taylor_kan_layers.py:40-195      TaylorKANConvNDLayer/2D      TaylorKANConvNDLayer / TaylorKANConv2DLayer
   jacobi_kan_layers.py:55-199      JacobiKANConvNDLayer/2D      JacobiKANConvNDLayer / JacobiKANConv2DLayer
   fourier_kan_layers.py:63-231     FourierKANConvNDLayer/2D     FourierKANConvNDLayer / FourierKANConv2DLayer  (own basis kind)
+  legendre_kan_layers.py:50-183    LegendreKANConvNDLayer/2D    LegendreKANConvNDLayer / LegendreKANConv2DLayer
+  bersnstein_kan_layers.py:63-201  BersnsteinKANConvNDLayer/2D  BersnsteinKANConvNDLayer / BersnsteinKANConv2DLayer
 
 The first seven share one shape (e.g. lucas_kan_layers.py:176-199):
     y = Dropout(PReLU(norm(conv(act(x), W_base) + conv(basis(tanh x), W_poly))))
@@ -406,3 +408,123 @@ class JacobiKANConv2DLayer(JacobiKANConvNDLayer):
         super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, conv_w_fun=torch.nn.functional.conv2d, input_dim=input_dim,
                          output_dim=output_dim, degree=degree, kernel_size=kernel_size, base_activation=base_activation, a=a, b=b,
                          groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2, dropout=dropout, **norm_kwargs)
+
+
+# ------------------------------------------------------------------------------------------- Legendre / Bernstein
+class _PlaneMajorPolyLayer(_HipLayer):
+    """Common body of the 'torchkan-style' conv layers (legendre / bersnstein / jacobi _kan_layers.py): identity base branch,
+    one ``poly_weights`` parameter [G, O/G, C/G*(degree+1), k, k], output = base_activation(norm(base + poly))."""
+
+    def _setup_pm(self, conv_class, norm_class, conv_w_fun, input_dim, output_dim, degree, kernel_size, base_activation, groups, padding,
+                  stride, dilation, dropout, ndim, norm_kwargs):
+        _need_conv2d(conv_class, ndim)
+        self.degree, self.kernel_size = degree, kernel_size
+        self.padding, self.stride, self.dilation, self.groups = padding, stride, dilation, groups
+        self.base_activation = base_activation
+        self.conv_w_fun, self.ndim, self.norm_kwargs = conv_w_fun, ndim, norm_kwargs
+        self.dropout = _dropout2d(dropout)
+        _check_groups(groups, input_dim, output_dim)
+        if degree < 1 or degree > 10:
+            raise NotImplementedError("this layer on the HIP path needs 1 <= degree <= 10")
+        if not isinstance(kernel_size, int):
+            raise TypeError("an int kernel_size is required (the reference builds poly_weights from `kernel_size` repeated ndim times)")
+        cg, og = input_dim // groups, output_dim // groups
+        self.base_conv = nn.ModuleList([conv_class(cg, og, kernel_size, stride, padding, dilation, groups=1, bias=False)
+                                        for _ in range(groups)])
+        self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
+        self.poly_weights = nn.Parameter(torch.randn(groups, og, cg * (degree + 1), *([kernel_size] * ndim)))
+        for conv in self.base_conv:
+            nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
+        nn.init.kaiming_uniform_(self.poly_weights, nonlinearity='linear')
+
+    def _norm_act(self, z, og):
+        G = self.groups
+        if _fusable_instnorm(self.layer_norm):
+            gam, bet = self._norm_affine(self.layer_norm)
+            y = ops.instance_norm(z, torch.cat(gam) if gam is not None else None, torch.cat(bet) if bet is not None else None,
+                                  eps=self.layer_norm[0].eps)
+        else:
+            parts = []
+            for g in range(G):
+                zg = z[:, g * og:(g + 1) * og]
+                if isinstance(self.layer_norm[g], nn.LayerNorm):
+                    zg = self.layer_norm[g](zg.reshape(zg.shape[0], -1)).view(zg.shape)
+                else:
+                    zg = self.layer_norm[g](zg)
+                parts.append(zg)
+            y = torch.cat(parts, dim=1)
+        return self.base_activation(y)
+
+
+class LegendreKANConvNDLayer(_PlaneMajorPolyLayer):
+    """legendre_kan_layers.py:50-158: base_conv(x) + conv(P_0..P_degree(x_n), poly_weights[g]) -> norm -> SiLU, with
+    x_n = 2 (x - min) / (max - min) - 1 over the WHOLE group tensor (:130; batch-coupled, so not data-parallel invariant),
+    dropout on x_n (:132-133), planes concatenated plane-major k*C + c (:124).  The normalisation is two torch reductions
+    (autograd carries the min / max gradients); the HIP conv stage evaluates the recurrence on x_n as a second input."""
+
+    def __init__(self, conv_class, norm_class, conv_w_fun, input_dim, output_dim, degree, kernel_size, groups=1, padding=0, stride=1,
+                 dilation=1, dropout: float = 0.0, ndim: int = 2, **norm_kwargs):
+        super().__init__()
+        self.input_dim, self.output_dim = input_dim, output_dim
+        self._setup_pm(conv_class, norm_class, conv_w_fun, input_dim, output_dim, degree, kernel_size, nn.SiLU(), groups, padding, stride,
+                       dilation, dropout, ndim, norm_kwargs)
+
+    def conv_spec(self) -> ops.ConvSpec:
+        n = self.degree + 1     # P_{k} = ((2k-1) x P_{k-1} - (k-1) P_{k-2}) / k   (legendre_kan_layers.py:119-122)
+        c = (1.0, 1.0, 0.0, [((2.0 * k - 1.0) / k, 0.0, -(k - 1.0) / k) for k in range(2, n)])
+        return self._spec(kind=L.BASIS_POLY, n_basis=n, order=0, act=L.ACT_IDENTITY, p0=0.0, p1=0.0, table=_table(c, n))
+
+    def forward(self, x):
+        G, n = self.groups, self.degree + 1
+        og, cg, k = self.output_dim // G, self.input_dim // G, self.kernel_size
+        B, _, H, W = x.shape
+        xg = x.reshape(B, G, cg, H, W)
+        lo, hi = xg.amin(dim=(0, 2, 3, 4), keepdim=True), xg.amax(dim=(0, 2, 3, 4), keepdim=True)
+        xn = (2 * (xg - lo) / (hi - lo) - 1).reshape(B, G * cg, H, W)
+        if self.dropout is not None:
+            xn = self.dropout(xn)
+        ws = [self.poly_weights[g].view(og, n, cg, k, k).transpose(1, 2).reshape(og, cg * n, k, k) for g in range(G)]
+        z = ops.kan_conv(self.conv_spec(), x, xn.contiguous(), [m.weight for m in self.base_conv], ws)
+        return self._norm_act(z, og)
+
+
+class LegendreKANConv2DLayer(LegendreKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree=3, groups=1, padding=0, stride=1, dilation=1,
+                 dropout: float = 0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(nn.Conv2d, norm_layer, torch.nn.functional.conv2d, input_dim, output_dim, degree, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2, dropout=dropout, **norm_kwargs)
+
+
+class BersnsteinKANConvNDLayer(_PlaneMajorPolyLayer):
+    """bersnstein_kan_layers.py:63-179.  The reference's de Casteljau loop starts from ALL-ONES coefficients (:122), and
+    b_i (1 - t) + b_{i+1} t with b = 1 stays 1: every one of its degree+1 'Bernstein' planes is the constant 1 (to an ulp),
+    with zero gradient w.r.t. x.  This layer reproduces exactly that: base_conv(x) + conv(ones, poly_weights[g]) -> norm ->
+    base_activation, channel index c*(degree+1) + k (:135-136).  Dropout on sigmoid(x) (:148-149) cannot change a constant
+    basis and is therefore a no-op here as it is there."""
+
+    def __init__(self, conv_class, norm_class, conv_w_fun, input_dim, output_dim, degree, kernel_size, base_activation=nn.SiLU, groups=1,
+                 padding=0, stride=1, dilation=1, dropout: float = 0.0, ndim: int = 2, **norm_kwargs):
+        super().__init__()
+        self.inputdim, self.outdim = input_dim, output_dim
+        self._setup_pm(conv_class, norm_class, conv_w_fun, input_dim, output_dim, degree, kernel_size,
+                       base_activation() if base_activation is not None else nn.Identity(), groups, padding, stride, dilation, dropout,
+                       ndim, norm_kwargs)
+
+    def conv_spec(self) -> ops.ConvSpec:
+        n = self.degree + 1
+        c = (1.0, 0.0, 1.0, [(0.0, 1.0, 0.0) for _ in range(2, n)])          # T_k == 1, dT_k/dx == 0
+        return self._spec(kind=L.BASIS_POLY, n_basis=n, order=1, act=L.ACT_IDENTITY, p0=0.0, p1=0.0, table=_table(c, n))
+
+    def forward(self, x):
+        G = self.groups
+        og = self.outdim // G
+        z = ops.kan_conv(self.conv_spec(), x, None, [m.weight for m in self.base_conv], [self.poly_weights[g] for g in range(G)])
+        return self._norm_act(z, og)
+
+
+class BersnsteinKANConv2DLayer(BersnsteinKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, base_activation=nn.SiLU, degree=3, groups=1, padding=0, stride=1, dilation=1,
+                 dropout: float = 0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
+        super().__init__(nn.Conv2d, norm_layer, torch.nn.functional.conv2d, input_dim, output_dim, degree, kernel_size,
+                         base_activation=base_activation, groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2,
+                         dropout=dropout, **norm_kwargs)

@@ -261,6 +261,44 @@ def fourierkan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_fourier: Sequence[T
     return _per_group(x, groups, one)
 
 
+def legendrekan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, *, degree: int, stride=1, padding=0, dilation=1,
+                       groups: int = 1, norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None,
+                       pre_norm_out: Optional[list] = None) -> Tensor:
+    """legendre_kan_layers.py:126-158: SiLU(norm(conv(x, W_b) + conv(P(x_n), poly_weights[g]))), x_n = 2(x - min)/(max - min) - 1
+    over the whole group tensor (:130), P_0 = 1, P_1 = x_n, P_{n+1} = ((2n+1) x_n P_n - n P_{n-1})/(n+1) (:109-124), planes
+    concatenated plane-major."""
+    def one(xg, g):
+        xn = 2 * (xg - xg.min()) / (xg.max() - xg.min()) - 1
+        p = [torch.ones_like(xn), xn]
+        for n in range(1, degree):
+            p.append(((2.0 * n + 1.0) * xn * p[-1] - n * p[-2]) / (n + 1.0))
+        z = _conv(xg, w_base[g], stride, padding, dilation) + _conv(torch.cat(p, dim=1), poly_weights[g], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        return F.silu(F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z))
+    return _per_group(x, groups, one)
+
+
+def bersnsteinkan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, *, degree: int,
+                         act: Optional[Callable[[Tensor], Tensor]], stride=1, padding=0, dilation=1, groups: int = 1,
+                         norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
+    """bersnstein_kan_layers.py:120-169, restated literally: the de Casteljau sweep over all-ones start coefficients on
+    t = sigmoid(x) (which leaves every plane at 1 up to rounding), planes channel-major c*(degree+1) + k."""
+    def one(xg, g):
+        t = torch.sigmoid(xg).unsqueeze(-1)
+        b = torch.ones(xg.shape + (degree + 1,), dtype=xg.dtype, device=xg.device)
+        for j in range(1, degree + 1):
+            m = degree + 1 - j
+            b = torch.cat((b[..., :m] * (1 - t) + b[..., 1:m + 1] * t, b[..., m:]), dim=-1)
+        planes = b.moveaxis(-1, 2).flatten(1, 2)
+        z = _conv(xg, w_base[g], stride, padding, dilation) + _conv(planes, poly_weights[g], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        return n if act is None else act(n)
+    return _per_group(x, groups, one)
+
+
 # --------------------------------------------------------------------------- whole-model oracle
 VGG11_CFG = [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512]
 

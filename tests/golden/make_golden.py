@@ -111,10 +111,11 @@ CASES = [
 # ---- three-term-recurrence polynomial families (section 8(f) rank 3); appended so that the seeds of the cases above stay put
 POLY_FAMILIES = {"bessel": "BesselKANConv2DLayer", "fibonacci": "FibonacciKANConv2DLayer", "gegenbauer": "GegenbauerKANConv2DLayer",
                  "hermite": "HermiteKANConv2DLayer", "laguerre": "LaguerreKANConv2DLayer", "lucas": "LucasKANConv2DLayer",
-                 "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer", "fourier": "FourierKANConv2DLayer"}
+                 "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer", "fourier": "FourierKANConv2DLayer",
+                 "legendre": "LegendreKANConv2DLayer", "bersnstein": "BersnsteinKANConv2DLayer"}
 POLY_EXTRA = {"gegenbauer": {"alpha_param": 0.7}, "laguerre": {"alpha": 1.0}, "jacobi": {"a": 1.0, "b": 0.5}}
 POLY_CASES = []
-for _fam in [f for f in POLY_FAMILIES if f != "fourier"]:
+for _fam in [f for f in POLY_FAMILIES if f not in ("fourier", "legendre", "bersnstein")]:
     POLY_CASES.append(C(_fam, "tiny", 2, 3, 4, 8, 8, degree=3, extra=POLY_EXTRA.get(_fam, {})))
     POLY_CASES.append(C(_fam, "deg5g2", 2, 4, 6, 7, 5, groups=2, degree=5, act="silu", xs=1.5, extra=POLY_EXTRA.get(_fam, {})))
 POLY_CASES += [
@@ -130,6 +131,12 @@ POLY_CASES += [
     C("fourier", "g5g2", 2, 4, 6, 7, 5, groups=2, degree=5, act="silu", xs=1.5),
     C("fourier", "g7_x10", 2, 3, 4, 8, 8, degree=7, xs=10.0),                  # large arguments: fl(k*x) rounding as the reference
     C("fourier", "g1_affine_s2", 2, 4, 6, 9, 9, s=2, degree=1, norm_kwargs={"affine": True}),
+    # LegendreKAN (batch-global min/max normalisation, SiLU output) and BersnsteinKAN (constant-one planes)
+    C("legendre", "tiny", 2, 3, 4, 8, 8, degree=3),
+    C("legendre", "deg5g2", 2, 4, 6, 7, 5, groups=2, degree=5, xs=1.5),
+    C("legendre", "s2_affine", 3, 4, 6, 9, 9, s=2, degree=4, norm_kwargs={"affine": True}),
+    C("bersnstein", "tiny", 2, 3, 4, 8, 8, degree=3),
+    C("bersnstein", "deg4g2_gelu", 2, 4, 6, 7, 5, groups=2, degree=4, act="gelu", xs=2.0),
 ]
 
 
@@ -144,6 +151,8 @@ def build_ref(c):
             kw["base_activation"] = ACTS[c["act"]]
         if c["kind"] == "fourier":
             return REF_LAYERS.FourierKANConv2DLayer(c["C"], c["O"], grid_size=c["degree"], **kw)
+        if c["kind"] == "legendre":
+            kw.pop("base_activation", None)
         return getattr(REF_LAYERS, POLY_FAMILIES[c["kind"]])(c["C"], c["O"], degree=c["degree"], **kw)
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:
@@ -192,6 +201,12 @@ def oracle_forward(c, layer, x, pre):
     if c["kind"] == "jacobi":
         return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
                                   a=layer.a, b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "legendre":
+        return O.legendrekan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
+                                    norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "bersnstein":
+        return O.bersnsteinkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
+                                      act=ACT_FN[c.get("act", "silu")], norm=norms, pre_norm_out=pre, **geo)
     if c["kind"] == "fourier":
         return O.fourierkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"fourier_conv.{g}.weight"] for g in range(G)],
                                    [sd[f"prelus.{g}.weight"] for g in range(G)], grid_size=layer.grid_size,

@@ -15,7 +15,8 @@ TOL_Y, TOL_DX, TOL_DW = 1e-5, 1e-5, 5e-5
 
 POLY = {"bessel": "BesselKANConv2DLayer", "fibonacci": "FibonacciKANConv2DLayer", "gegenbauer": "GegenbauerKANConv2DLayer",
         "hermite": "HermiteKANConv2DLayer", "laguerre": "LaguerreKANConv2DLayer", "lucas": "LucasKANConv2DLayer",
-        "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer", "fourier": "FourierKANConv2DLayer"}
+        "taylor": "TaylorKANConv2DLayer", "jacobi": "JacobiKANConv2DLayer", "fourier": "FourierKANConv2DLayer",
+        "legendre": "LegendreKANConv2DLayer", "bersnstein": "BersnsteinKANConv2DLayer"}
 
 
 def layer_kwargs(c):
@@ -26,7 +27,7 @@ def layer_kwargs(c):
     if c["kind"] in POLY:
         kw.update(c.get("extra", {}))
         kw["grid_size" if c["kind"] == "fourier" else "degree"] = c["degree"]
-        if "act" in c:
+        if "act" in c and c["kind"] != "legendre":
             kw["base_activation"] = ACTS[c["act"]]
         return kw
     if c["kind"] == "bspline":
@@ -76,6 +77,12 @@ def oracle_forward(c, layer, x, pre=None):
     if c["kind"] == "jacobi":
         return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree, a=layer.a,
                                   b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "legendre":
+        return O.legendrekan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
+                                    norm=norms, pre_norm_out=pre, **geo)
+    if c["kind"] == "bersnstein":
+        return O.bersnsteinkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
+                                      act=ACT_FN[c.get("act", "silu")], norm=norms, pre_norm_out=pre, **geo)
     if c["kind"] == "fourier":
         return O.fourierkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"fourier_conv.{g}.weight"] for g in range(G)],
                                    [sd[f"prelus.{g}.weight"] for g in range(G)], grid_size=layer.grid_size,

@@ -146,7 +146,12 @@ def test_polynomial_family_surface():
 def test_factory_signatures_and_same_padding():
     F = K.CONV_KAN_FACTORY
     poly = {"BesselKAN", "FibonacciKAN", "GegenbauerKAN", "HermiteKAN", "JacobiKAN", "LaguerreKAN", "LucasKAN", "TaylorKAN"}
-    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "conv"} | poly
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "conv"} | poly
+    lg = F["LegendreKAN"](4, 6, 3, dilation=2)
+    assert (lg.padding, lg.dilation, lg.degree) == (2, 2, 3) and isinstance(lg.base_activation, nn.SiLU)
+    assert list(inspect.signature(F["LegendreKAN"]).parameters)[3] == "degree"
+    bs = F["BersnsteinKAN"](4, 6, 3, groups=2)
+    assert list(bs.state_dict()) == ["poly_weights", "base_conv.0.weight", "base_conv.1.weight"] and (bs.inputdim, bs.outdim) == (4, 6)
     assert inspect.signature(F["FourierKAN"]).parameters["grid_size"].default == 3
     fl = F["FourierKAN"](4, 6, 3, groups=2)
     assert list(fl.state_dict())[:4] == ["base_conv.0.weight", "base_conv.1.weight", "fourier_conv.0.weight", "fourier_conv.1.weight"]

@@ -123,8 +123,8 @@ def cpu_baseline(batch: int, iters: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kan_vgg11")
     ap.add_argument("--no-cpu-baseline", action="store_true")

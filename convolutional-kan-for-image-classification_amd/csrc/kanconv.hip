@@ -341,7 +341,7 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
 // Workgroup tile: TO = WO*64 outputs x TP = WP*64 output pixels, one 64x64 wave tile per wave (2x2 MFMA 32x32x2).
 // Pipeline per step: [expand + write step s into buffer b] barrier [issue global loads of step s+1] [MFMAs on b].
 template <int KIND, int FAST, int WO, int WP, int KC>
-__global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
+__global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fwd(
     const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp, float* __restrict__ z,
     DevGeom g, DevBasis bs, int Opad, int IPC, int n_chunks, int chunks_per_split, long long slab_elems, unsigned x_bytes, TilePerm perm,
     int tiles_o) {
@@ -477,7 +477,11 @@ __global__ __launch_bounds__(WO * WP * 64, 4) void k_conv_fwd(
     const int ao = w_o * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int cur = 0; ch < ch1; cur ^= 1) {
         stage(cur);
-        __syncthreads();                                   // (drains the async weight copy of this step: vmcnt(0))
+        // Every wave must have its own LDS-DMA weight rows landed before anyone reads them.  Waves that stage wait on
+        // their gathers anyway, but a wave with no unit to stage (IPC < item lanes, or the 512-thread tile) would reach
+        // the barrier with its copy in flight: the compiler does not tie global_load_lds to the barrier.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         ch = next_live(ch + 1);
         if (ch < ch1) issue(ch, cur ^ 1);
         const float* cW = sW + cur * (KC * TO);
@@ -647,7 +651,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     if (ch < ch1) issue(ch, 0);
     const int ar = w_r * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int cur = 0; ch < ch1; cur ^= 1) {
-        __syncthreads();                                   // drains this step's async copies (vmcnt(0)) and orders the buffers
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's async copies of the step have landed ...
+        __syncthreads();                                   // ... and so have everyone else's; also orders the two buffers
         ch = next_live(ch + 1);
         if (ch < ch1) issue(ch, cur ^ 1);
         const float* cW = smem + cur * (2 * KD * 128);
@@ -712,7 +717,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
 // pixels.  The expanded operand is written [pixel][row] (pad 1) so that both the per-pixel writes and the per-row
 // MFMA reads are bank-conflict free (2-way at worst on the writes, which ds_write_b32 absorbs).
 template <int KIND, int FAST, int WR, int WC>
-__global__ __launch_bounds__(WR * WC * 64, 4) void k_conv_bwd_weight(
+__global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
     DevGeom g, DevBasis bs, int Krows, int Opad, int n_chunks, int chunks_per_split, long long slab_elems,
     unsigned x_bytes, unsigned dz_bytes, int tiles_o) {
@@ -1139,8 +1144,7 @@ DevBasis dev_basis(const KanBasis* b) {
 // than ~1/6 of a step (latency of the serial slab loop on tiny outputs).
 double slab_cost_steps(double slab_bytes) { const double bw = slab_bytes / 4.0e6; return bw > 1.0 / 6.0 ? bw : 1.0 / 6.0; }
 
-int pick_splits(long long tiles, int chunks, int min_chunks, double slab_bytes) {
-    const long long SLOTS = 1024;
+int pick_splits(long long tiles, int chunks, int min_chunks, double slab_bytes, long long SLOTS = 1024) {
     int cap = chunks / min_chunks; if (cap < 1) cap = 1;
     if (cap > 1024) cap = 1024;
     int best = 1; double best_cost = -1;
@@ -1163,15 +1167,25 @@ int launch_ok(const char* what) {
     return 0;
 }
 
-struct FwdCfg { int TO, TP, tiles_o, tiles_p, chunks, splits; };
-FwdCfg fwd_cfg(const KanGeom* g, const KanPlan& pl) {
+int fast_variant(const KanBasis* b);
+// 256-output tiles (512 threads, 2 workgroups per CU): every expanded input value then feeds 256 outputs instead of 128,
+// which halves the staging work (basis evaluation + LDS writes: ~13 % of the forward kernel's time, measured by
+// ablation) per MFMA.  Offered where the compile-time basis specs exist and O is a multiple of 256.
+bool big_tiles(const KanBasis* b, const KanPlan& pl) {
+    static const int off = getenv("KAN_BIG") ? (atoi(getenv("KAN_BIG")) == 0) : 0;         // KAN_BIG=0: A/B switch (tuning only)
+    const int f = fast_variant(b);
+    return !off && pl.Opad % 256 == 0 && (f == 1 || f == 2 || f == 4);
+}
+struct FwdCfg { int TO, TP, tiles_o, tiles_p, chunks, splits, slots; };
+FwdCfg fwd_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     FwdCfg c;
-    c.TO = (pl.Opad % 128 == 0) ? 128 : 64;
+    c.TO = (big_tiles(b, pl) && !want_pix_major(g, b, PM_FWD)) ? 256 : (pl.Opad % 128 == 0) ? 128 : 64;   // (2x2 planes: -17 % with 256)
+    c.slots = c.TO == 256 ? 512 : 1024;
     c.TP = 128;
     c.tiles_o = pl.Opad / c.TO;
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
     c.chunks = pl.Kpad / pl.KC;
-    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * ngroups(g));
+    c.splits = pick_splits((long long)c.tiles_o * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * ngroups(g), c.slots);
     return c;
 }
 // With dead-tap skipping the tiles of one launch carry 4/9 ... 9/9 of the nominal work depending on their pixel
@@ -1208,8 +1222,7 @@ TilePerm balance_tiles(const int* weight, int n) {
     p.n = n;
     return p;
 }
-int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, double slab_bytes, int* max_splits) {
-    const long long SLOTS = 1024;
+int pick_target_steps(const LiveClass* cls, int ncls, int min_steps, double slab_bytes, int* max_splits, long long SLOTS = 1024) {
     int hi = 1;
     for (int i = 0; i < ncls; ++i) if (cls[i].live_steps > hi) hi = cls[i].live_steps;
     int best = hi; double best_cost = -1; int best_ms = 1;
@@ -1266,15 +1279,16 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.splits = pick_splits((long long)c.tiles_c * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->C * g->H * g->W * ngroups(g));
     return c;
 }
-struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits; };
-BwCfg bw_cfg(const KanGeom* g, const KanPlan& pl) {
+struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits, slots; };
+BwCfg bw_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     BwCfg c;
-    c.TO = (pl.Opad % 128 == 0) ? 128 : 64;
-    c.TR = c.TO == 128 ? 128 : 256;
+    c.TO = (big_tiles(b, pl) && !want_pix_major(g, b, PM_BWD_WEIGHT)) ? 256 : (pl.Opad % 128 == 0) ? 128 : 64;
+    c.slots = c.TO == 256 ? 512 : 1024;
+    c.TR = c.TO == 64 ? 256 : 128;
     c.tiles_r = ceil_div(pl.K, c.TR);
     c.tiles_o = pl.Opad / c.TO;
     c.chunks = ceil_div((long long)g->B * g->Ho * g->Wo, 16);
-    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o * ngroups(g), c.chunks, 16, 4.0 * pl.K * pl.Opad * ngroups(g));
+    c.splits = pick_splits((long long)c.tiles_r * c.tiles_o * ngroups(g), c.chunks, 16, 4.0 * pl.K * pl.Opad * ngroups(g), c.slots);
     return c;
 }
 
@@ -1300,23 +1314,23 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_slab_elems = (long long)g->B * g->y_bstride;
     pl->bwd_data_slab_elems = (long long)g->B * g->x_bstride;
     pl->bwd_weight_slab_elems = (long long)G * pl->K * pl->Opad;
-    pl->fwd_splits = fwd_cfg(g, *pl).splits;
+    pl->fwd_splits = fwd_cfg(g, b, *pl).splits;
     pl->bwd_data_splits = bd.splits;
-    pl->bwd_weight_splits = bw_cfg(g, *pl).splits;
+    pl->bwd_weight_splits = bw_cfg(g, b, *pl).splits;
     pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     if (want_pix_major(g, b, PM_FWD)) {          // forward: one class per output position; a tap holds C/IPC steps
-        LiveClass cls[16]; const int plane = g->Ho * g->Wo; FwdCfg fc = fwd_cfg(g, *pl);
+        LiveClass cls[16]; const int plane = g->Ho * g->Wo; FwdCfg fc = fwd_cfg(g, b, *pl);
         const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o * G;
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
-        pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * G, &pl->fwd_splits);
+        pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * G, &pl->fwd_splits, fc.slots);
     }
     if (want_pix_major(g, b, PM_BWD_WEIGHT)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
-        LiveClass cw[32]; BwCfg wc = bw_cfg(g, *pl);
+        LiveClass cw[32]; BwCfg wc = bw_cfg(g, b, *pl);
         const long long tiles_per_tap = (long long)ceil_div((long long)g->C * pl->P, wc.TR) * wc.tiles_o * G;
         for (int tap = 0; tap < T; ++tap) cw[tap] = LiveClass{tiles_per_tap, live_positions_for_tap(g, tap) * ceil_div(g->B, 16)};
-        pl->bwd_weight_target = pick_target_steps(cw, T, 16, 4.0 * pl->K * pl->Opad * G, &pl->bwd_weight_splits);
+        pl->bwd_weight_target = pick_target_steps(cw, T, 16, 4.0 * pl->K * pl->Opad * G, &pl->bwd_weight_splits, wc.slots);
     }
     if (want_pix_major(g, b, PM_BWD_DATA)) {     // bwd-data: one class per input position; a tap holds n_ob steps
         LiveClass cls[16]; const int plane = g->H * g->W;
@@ -1366,7 +1380,7 @@ int group_lanes(int HW) { int g = 4; while (g < 64 && g < HW) g <<= 1; return g;
 // ============================================================================ C ABI
 extern "C" {
 
-const char* kan_version(void) { return "kanconv 0.3 (gfx950, fp32 MFMA 32x32x2, 4 WG/CU pipeline)"; }
+const char* kan_version(void) { return "kanconv 0.4 (gfx950, fp32 MFMA 32x32x2, 128- and 256-output tiles)"; }
 const char* kan_last_error(void) { return g_err; }
 
 int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {
@@ -1439,7 +1453,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!x || !xn || !wp || !z) return fail("null tensor pointer");
-    FwdCfg c = fwd_cfg(g, pl);
+    FwdCfg c = fwd_cfg(g, b, pl);
     DevGeom dg = dev_geom(g);
     dg.pix_major = (x_pm && x == xn && want_pix_major(g, b, PM_FWD)) ? 1 : 0;      // (one copy serves both inputs only when they are the same)
     if (dg.pix_major) { x = x_pm; xn = x_pm; }
@@ -1469,7 +1483,11 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     } while (0)
     const int fast = fast_variant(b);
 #define KAN_FWD_FAST(KIND, F, KCV) do { if (c.TO == 128) KAN_FWD2(KIND, F, 2, 2, KCV); else KAN_FWD2(KIND, F, 1, 2, KCV); } while (0)
-    if (fast == 1) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 1, 18);
+    if (c.TO == 256 && fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 4, 2, 18);
+    else if (c.TO == 256 && fast == 2) KAN_FWD2(KAN_BASIS_BSPLINE, 2, 4, 2, 18);
+    else if (c.TO == 256 && fast == 4) KAN_FWD2(KAN_BASIS_CHEBY, 4, 4, 2, 16);
+    else if (c.TO == 256) return fail("internal: no 256-output forward kernel for this basis");
+    else if (fast == 1) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 1, 18);
     else if (fast == 2) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 2, 18);
     else if (fast == 3) KAN_FWD_FAST(KAN_BASIS_RBF, 3, 18);
     else if (fast == 4) KAN_FWD_FAST(KAN_BASIS_CHEBY, 4, 16);
@@ -1526,7 +1544,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !dwp) return fail("null tensor pointer");
-    BwCfg c = bw_cfg(g, pl);
+    BwCfg c = bw_cfg(g, b, pl);
     DevGeom dg = dev_geom(g);
     dg.pix_major = (x_pm && dz_pm && x == xn && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     if (dg.pix_major) { x = x_pm; xn = x_pm; dz = dz_pm; }
@@ -1537,11 +1555,15 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     int cps = dg.pix_major ? pl.bwd_weight_target : ceil_div(c.chunks, pl.bwd_weight_splits);
 #define KAN_BW(KIND, WR, WC) KAN_BW2(KIND, 0, WR, WC)
 #define KAN_BW2(KIND, FAST, WR, WC) \
-    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(256), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o)
+    hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(WR * WC * 64), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o)
 #define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
     const int fast = fast_variant(b);
 #define KAN_BW_FAST(KIND, F) do { if (c.TO == 128) KAN_BW2(KIND, F, 2, 2); else KAN_BW2(KIND, F, 4, 1); } while (0)
-    if (fast == 1) KAN_BW_FAST(KAN_BASIS_BSPLINE, 1);
+    if (c.TO == 256 && fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 2, 4);
+    else if (c.TO == 256 && fast == 2) KAN_BW2(KAN_BASIS_BSPLINE, 2, 2, 4);
+    else if (c.TO == 256 && fast == 4) KAN_BW2(KAN_BASIS_CHEBY, 4, 2, 4);
+    else if (c.TO == 256) return fail("internal: no 256-output weight-gradient kernel for this basis");
+    else if (fast == 1) KAN_BW_FAST(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BW_FAST(KAN_BASIS_BSPLINE, 2);
     else if (fast == 3) KAN_BW_FAST(KAN_BASIS_RBF, 3);
     else if (fast == 4) KAN_BW_FAST(KAN_BASIS_CHEBY, 4);

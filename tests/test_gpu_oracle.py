@@ -117,6 +117,16 @@ def test_grouped_single_launch_vs_oracle(case, gpu_lib):
     _compare(layer, cfg, torch.randn(B, C, H, H), tol_scale=8.0 if H == 2 else 2.0)
 
 
+@pytest.mark.parametrize("gs,C,O,H,B", [(8, 64, 128, 8, 16), (7, 32, 256, 6, 8), (6, 40, 70, 9, 4)])
+def test_many_planes_single_item_steps(gs, C, O, H, B, gpu_lib):
+    """P >= 10 planes leave room for ONE (tap, channel) item per LDS step, so half the forward kernel's waves have nothing to
+    stage; they must still wait for their own async weight copy before the step barrier (a wave that skipped the wait
+    raced the readers of its rows)."""
+    torch.manual_seed(gs)
+    layer = K.KANConv2DLayer(C, O, 3, padding=1, grid_size=gs, base_activation=nn.SiLU)
+    _compare(layer, _cfg("bspline", C, O, act="silu", grid_size=gs), torch.randn(B, C, H, H), tol_scale=2.0)
+
+
 def test_nan_and_out_of_grid_inputs(gpu_lib):
     """x outside the knot span has all bases zero (kan_layers.py:209); NaN inputs propagate through the base branch only."""
     torch.manual_seed(1)

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
 // zero), x 128 input pixels.  Depth steps: (tap, 16 outputs); weights come from the wd layout (straight 16 x 128
 // copy), dz is gathered at the output position each (input pixel, tap) pair feeds.
 // Epilogue, one half at a time (32 KB of LDS): G half-tile -> LDS, then dx = sum_p plane_p'(x) * G_p.
-template <int KIND>
+template <int KIND, int FAST>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
     float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CH, int n_ct, int n_ob, int Opad16,
@@ -674,6 +674,61 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const bool split_out = (dxn != nullptr);
     float* dxs = dx + (size_t)blockIdx.z * slab_elems;
     float* dxns = split_out ? dxn + (size_t)blockIdx.z * slab_elems : nullptr;
+    if (FAST != 0) {
+        // Compile-time spec (B-spline grid 5 / order 3, P = 9, CH = 7; FAST 1: SiLU, 2: GELU), single input tensor.
+        // All x values of this thread's (channel, pixel) pairs are fetched up front (the generic loop below pays one
+        // dependent global-load latency per channel), the cubic's derivative comes from the closed form (kan_device.h,
+        // bspline_uniform<true>, S = 3) and only the <= 4 live planes of G are read back from LDS.
+        constexpr int FP = 9, FCH = 7, NIT = (FCH + 1) / 2;
+        float xv[2][NIT]; unsigned ok = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const bool v = cl < FCH && c < g.C && pv;
+                xv[half][it] = v ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
+                ok |= (v ? 1u : 0u) << (half * NIT + it);
+            }
+        const float hh = 0.5f * bs.inv_h;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (w_r == half) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            smem[(mi * 32 + mfma_row(r, lane)) * TP + w_p * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!((ok >> (half * NIT + it)) & 1u)) continue;
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const float xa = half == 0 ? xv[0][it] : xv[1][it];
+                float dact;
+                if (FAST == 1) {
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xa * -1.44269504088896340736f));
+                    dact = sg * (1.0f + xa * (1.0f - sg));
+                } else dact = kan_act_grad(KAN_ACT_GELU, xa);
+                const float* G = smem + (cl * FP) * TP + pxl;
+                float sum = dact * G[0];
+                if (xa >= bs.g0 && xa < bs.gN) {                       // NaN fails both, as the reference's indicator
+                    const int i = min((int)((xa - bs.g0) * bs.inv_h), 10);
+                    const float u = fminf(fmaxf((xa - sTab[i]) * bs.inv_h, 0.f), 1.f), v = 1.f - u, u2 = u * u;
+                    const float n0 = -hh * v * v, n1 = hh * (3.f * u2 - 4.f * u), n2 = hh * (-3.f * u2 + 2.f * u + 1.f), n3 = hh * u2;
+                    const int j0 = i - 3;                              // bases j0 .. j0+3, kept where 0 <= j < 8
+                    sum += ((unsigned)j0 < 8u ? n0 * G[(1 + j0) * TP] : 0.f) + ((unsigned)(j0 + 1) < 8u ? n1 * G[(2 + j0) * TP] : 0.f)
+                         + ((unsigned)(j0 + 2) < 8u ? n2 * G[(3 + j0) * TP] : 0.f) + ((unsigned)(j0 + 3) < 8u ? n3 * G[(4 + j0) * TP] : 0.f);
+                }
+                dxs[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] = sum;
+            }
+        }
+        return;
+    }
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         __syncthreads();                                   // previous readers of smem are done
@@ -1528,13 +1583,18 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
         }
         perm = balance_tiles(w, c.tiles_p);
     }
-#define KAN_BD(KIND) \
-    hipLaunchKernelGGL((k_conv_bwd_data<KIND>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
-    if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
+#define KAN_BD(KIND) KAN_BD2(KIND, 0)
+#define KAN_BD2(KIND, FAST) \
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
+    const int fast = (x == xn && !dxn) ? fast_variant(b) : 0;
+    if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);
+    else if (fast == 2) KAN_BD2(KAN_BASIS_BSPLINE, 2);
+    else if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_BD(KAN_BASIS_FOURIER);
     else KAN_BD(KAN_BASIS_CHEBY);
+#undef KAN_BD2
 #undef KAN_BD
     return launch_ok("conv_bwd_data");
 }

@@ -160,6 +160,28 @@ __global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, f
     }
 }
 
+// Many-slab weight gradients (a 3-channel first layer is ONE row tile, so its pixel axis is cut ~300 ways): fold all
+// slabs into slab 0 with 4 slab lanes per element and 4 partial sums per lane, then unpack a single slab.  Summation
+// order is fixed (deterministic).  Block = 64 elements x 4 slab lanes.
+__global__ __launch_bounds__(256) void k_fold_slabs(float* __restrict__ slabs, int n_slabs, long long slab_elems, long long n) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, sg = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (i < n) {
+        const float* p = slabs + i;
+        int sl = sg;
+        for (; sl + 12 < n_slabs; sl += 16) {
+            a0 += p[(size_t)sl * slab_elems]; a1 += p[(size_t)(sl + 4) * slab_elems];
+            a2 += p[(size_t)(sl + 8) * slab_elems]; a3 += p[(size_t)(sl + 12) * slab_elems];
+        }
+        for (; sl < n_slabs; sl += 4) a0 += p[(size_t)sl * slab_elems];
+    }
+    part[sg][e] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (sg == 0 && i < n) slabs[i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+}
+
 // Backward-data weight layout, derived from the forward one by a per-tap tiled transpose:
 //   wd[(tap * Opad16 + o)][ct * 128 + half * 64 + cl * P + p] = wp[k((tap*C+c), p)][o],
 //   c = (ct*2 + half) * CH + cl,  CH = 64 / P whole channels per 64-column half
@@ -1005,8 +1027,17 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
     const bool need_sum = (n_slabs > 1) || (z_out != z);
     float s = 0.f;
     if (act) for (int i = sub; i < HW; i += G) {
-        float v = z[base + i];
-        for (int sl = 1; sl < n_slabs; ++sl) v += z[base + i + (size_t)sl * slab_elems];
+        // split-K slabs: four independent partial sums keep four loads in flight (a 32-slab 2x2-plane layer spent its
+        // whole time in this dependent chain); fixed order => deterministic
+        const float* zp = z + base + i;
+        float v0 = zp[0], v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int sl = 1;
+        for (; sl + 4 <= n_slabs; sl += 4) {
+            v0 += zp[(size_t)sl * slab_elems]; v1 += zp[(size_t)(sl + 1) * slab_elems];
+            v2 += zp[(size_t)(sl + 2) * slab_elems]; v3 += zp[(size_t)(sl + 3) * slab_elems];
+        }
+        for (; sl < n_slabs; ++sl) v0 += zp[(size_t)sl * slab_elems];
+        const float v = (v0 + v1) + (v2 + v3);
         if (need_sum) z_out[base + i] = v;
         s += v;
     }
@@ -1424,11 +1455,17 @@ void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, 
                    int span) {
     int ppb = 256 / G;
     int blocks = ceil_div(planes, ppb);
-    if (blocks > 2048) blocks = 2048;
+    const int cap = (long long)planes * HW < (4ll << 20) ? 512 : 2048;       // small tensors: fewer same-address atomics on dprelu
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
                        dbeta, dprelu, planes, Cn, HW, bs, span);
 }
-int group_lanes(int HW) { int g = 4; while (g < 64 && g < HW) g <<= 1; return g; }
+// Lanes per (b, channel) plane.
+int group_lanes(int HW) {          // (more elements per lane was measured: no gain)
+    int g = 4;
+    while (g < 64 && g < HW) g <<= 1;
+    return g;
+}
 
 }  // namespace
 
@@ -1487,12 +1524,18 @@ int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const Ka
     const int T = g->kh * g->kw, G = ngroups(g);
     const long long dwp_gs = (long long)pl.K * pl.Opad;
     PackGeo q = pack_geo(g, b, pl, true);
+    int n_slabs = pl.bwd_weight_splits;
+    if (n_slabs >= 32) {                                      // (dwp is the caller's scratch: slab 0 becomes the sum)
+        hipLaunchKernelGGL(k_fold_slabs, dim3(ceil_div(pl.bwd_weight_slab_elems, 64)), dim3(256), 0, st, const_cast<float*>(dwp), n_slabs,
+                           pl.bwd_weight_slab_elems, pl.bwd_weight_slab_elems);
+        n_slabs = 1;
+    }
     if (hb) {
         dim3 grid(ceil_div(g->C * T, 32), ceil_div(g->O, 32), G);
-        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, q, 0, pl.bwd_weight_splits, pl.bwd_weight_slab_elems, dwp_gs);
+        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, q, 0, n_slabs, pl.bwd_weight_slab_elems, dwp_gs);
     }
     dim3 grid(ceil_div(g->C * b->n_basis * T, 32), ceil_div(g->O, 32), G);
-    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_basis, q, 1, pl.bwd_weight_splits, pl.bwd_weight_slab_elems, dwp_gs);
+    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_basis, q, 1, n_slabs, pl.bwd_weight_slab_elems, dwp_gs);
     return launch_ok("unpack");
 }
 

@@ -142,7 +142,8 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
                         const KanGeom* geom, const KanBasis* basis, const float* x_pm, const float* dz_pm, void* stream);
 
 /* Sum the dwp slabs and scatter back to the reference layouts (inverse of kan_pack_weights; stacked [G,...] when
- * geom->groups = G).  dw_base may be NULL iff there is no base branch. */
+ * geom->groups = G).  dw_base may be NULL iff there is no base branch.  dwp is scratch: with >= 32 slabs the sum is
+ * first folded into slab 0 in place. */
 int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis,
                      const KanGeom* geom, const KanBasis* basis, void* stream);
 

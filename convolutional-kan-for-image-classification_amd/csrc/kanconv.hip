@@ -22,6 +22,34 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// ds_read_b32 x4 with immediate byte offsets (asm: the compiler cannot see these loads, so LDS_WAIT4 both waits and
+// "touches" the destination registers to order their consumers after the wait)
+#define LDS_READ4(r0, r1, r2, r3, addrA, addrB, o0, o1, o2, o3)                                                        \
+    asm volatile("ds_read_b32 %0, %4 offset:%6\n\tds_read_b32 %1, %4 offset:%7\n\tds_read_b32 %2, %5 offset:%8\n\tds_read_b32 %3, %5 offset:%9" \
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addrA), "v"(addrB), "n"(o0), "n"(o1), "n"(o2), "n"(o3) : "memory")
+#define LDS_WAIT4(r0, r1, r2, r3, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) :: "memory")
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p; }
+// One LDS step of 2x2 MFMA tiles per wave: NK k-pairs, operand A rows LDA floats apart at LDS byte address addrA (k-row
+// kh2 already folded in), operand B likewise; reads software-pipelined one k-pair ahead (see the forward kernel).
+#define KAN_MFMA_STEP(NK, addrA, LDA, addrB, LDB)                                                                                   \
+    do {                                                                                                                           \
+        float fa_[2][2], fb_[2][2];                                                                                                \
+        LDS_READ4(fa_[0][0], fa_[0][1], fb_[0][0], fb_[0][1], addrA, addrB, 0, 32 * 4, 0, 32 * 4);                                 \
+        _Pragma("unroll") for (int kk = 0; kk < (NK); ++kk) {                                                                       \
+            const int c_ = kk & 1, n_ = c_ ^ 1;                                                                                    \
+            if (kk + 1 < (NK)) {                                                                                                   \
+                LDS_READ4(fa_[n_][0], fa_[n_][1], fb_[n_][0], fb_[n_][1], addrA, addrB, (2 * (kk + 1)) * (LDA) * 4,                \
+                          (2 * (kk + 1)) * (LDA) * 4 + 128, (2 * (kk + 1)) * (LDB) * 4, (2 * (kk + 1)) * (LDB) * 4 + 128);         \
+                LDS_WAIT4(fa_[c_][0], fa_[c_][1], fb_[c_][0], fb_[c_][1], 4);                                                      \
+            } else {                                                                                                               \
+                LDS_WAIT4(fa_[c_][0], fa_[c_][1], fb_[c_][0], fb_[c_][1], 0);                                                      \
+            }                                                                                                                      \
+            acc[0][0] = MFMA32(fa_[c_][0], fb_[c_][0], acc[0][0]);                                                                 \
+            acc[0][1] = MFMA32(fa_[c_][0], fb_[c_][1], acc[0][1]);                                                                 \
+            acc[1][0] = MFMA32(fa_[c_][1], fb_[c_][0], acc[1][0]);                                                                 \
+            acc[1][1] = MFMA32(fa_[c_][1], fb_[c_][1], acc[1][1]);                                                                 \
+        }                                                                                                                          \
+    } while (0)
 
 namespace {
 
@@ -508,16 +536,12 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
         if (ch < ch1) issue(ch, cur ^ 1);
         const float* cW = sW + cur * (KC * TO);
         const float* cE = sE + cur * (KC * TP);
-#pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) {
-            const int krow = 2 * kk + kh2;
-            float a0 = cW[krow * TO + ao], a1 = cW[krow * TO + ao + 32];
-            float b0 = cE[krow * TP + bp], b1 = cE[krow * TP + bp + 32];
-            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
-        }
+        // Operand fetch in explicit ISA: four ds_read_b32 per k-pair with IMMEDIATE offsets (the compiler's ds_read2 form
+        // needs a v_add per address, and VALU instructions cost matrix time on this chip), and the reads of k-pair kk+1
+        // are issued before the MFMAs of kk (lgkmcnt(4) = "all but the newest four have landed"; LDS returns in order),
+        // so one wave alone keeps the matrix pipe fed across the LDS latency.
+        const unsigned aw = lds_addr(cW + kh2 * TO + ao), ae = lds_addr(cE + kh2 * TP + bp);
+        KAN_MFMA_STEP(KC / 2, aw, TO, ae, TP);
     }
 
     // ---- store: column (lane) = pixel => coalesced along the plane
@@ -679,16 +703,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         if (ch < ch1) issue(ch, cur ^ 1);
         const float* cW = smem + cur * (2 * KD * 128);
         const float* cG = cW + KD * 128;
-#pragma unroll
-        for (int kk = 0; kk < KD / 2; ++kk) {
-            const int krow = 2 * kk + kh2;
-            float a0 = cW[krow * 128 + ar], a1 = cW[krow * 128 + ar + 32];
-            float b0 = cG[krow * TP + bp], b1 = cG[krow * TP + bp + 32];
-            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
-        }
+        const unsigned aw = lds_addr(cW + kh2 * 128 + ar), ag = lds_addr(cG + kh2 * TP + bp);
+        KAN_MFMA_STEP(KD / 2, aw, 128, ag, TP);
     }
 
     // ---- epilogue: per 64-row half, G -> LDS, contract the P planes of each channel with plane'(x)
@@ -964,16 +980,8 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         if (ch < ch1) issue(ch);
         const float* cE = sE + cur * (KPX * LDE) + MRG;
         const float* cZ = sZ + cur * (KPX * LDZ);
-#pragma unroll
-        for (int kk = 0; kk < KPX / 2; ++kk) {
-            const int krow = 2 * kk + kh2;
-            float a0 = cE[krow * LDE + ar], a1 = cE[krow * LDE + ar + 32];
-            float b0 = cZ[krow * LDZ + bo], b1 = cZ[krow * LDZ + bo + 32];
-            acc[0][0] = MFMA32(a0, b0, acc[0][0]);
-            acc[0][1] = MFMA32(a0, b1, acc[0][1]);
-            acc[1][0] = MFMA32(a1, b0, acc[1][0]);
-            acc[1][1] = MFMA32(a1, b1, acc[1][1]);
-        }
+        const unsigned ae = lds_addr(cE + kh2 * LDE + ar), az = lds_addr(cZ + kh2 * LDZ + bo);
+        KAN_MFMA_STEP(KPX / 2, ae, LDE, az, LDZ);
     }
 
     float* out = dwp + (size_t)blockIdx.z * slab_elems;

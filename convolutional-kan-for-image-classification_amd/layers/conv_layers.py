@@ -13,7 +13,9 @@ preserves ``state_dict`` keys (``base_conv.0.weight`` ...), lets ``load_state_di
 between this package and the reference in both directions, and keeps callers that walk
 ``.modules()`` for ``nn.Conv2d`` (models/kan_alexnet.py:236-241) working.
 
-Only the 2-D layers are implemented (1-D / 3-D shims are SURVEY.md section 8(f) "next").
+The 2-D layers are the hot path.  The 1-D shims (KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv1DLayer:
+kan_layers.py:287-297, fast_kan_layers.py:151-162, cheby_kan_layers.py:134-141) run on the same kernels by viewing
+[B, C, L] as [B, C, 1, L] with a (1, k) kernel; 3-D layers are not built.
 """
 from __future__ import annotations
 
@@ -51,8 +53,10 @@ def _act_code(module: nn.Module) -> int:
     return code
 
 
-def _dropout2d(p: float):
-    return nn.Dropout2d(p=p) if p > 0 else None
+def _dropout2d(p: float, ndim: int = 2):
+    if p <= 0:
+        return None
+    return nn.Dropout1d(p=p) if ndim == 1 else nn.Dropout2d(p=p)
 
 
 def _check_groups(groups, input_dim, output_dim):
@@ -71,19 +75,46 @@ def _filter_norm_kwargs(norm_class, norm_kwargs):
 
 
 def _fusable_instnorm(mods) -> bool:
-    """True when every per-group norm is a plain InstanceNorm2d (instance statistics in train and eval)."""
-    return all(type(m) is nn.InstanceNorm2d and not m.track_running_stats for m in mods)
+    """True when every per-group norm is a plain InstanceNorm1d/2d (instance statistics in train and eval)."""
+    return all(type(m) in (nn.InstanceNorm2d, nn.InstanceNorm1d) and not m.track_running_stats for m in mods)
 
 
 def _need_conv2d(conv_class, ndim):
-    if conv_class is not nn.Conv2d or ndim != 2:
-        raise NotImplementedError("only the 2-D layers are implemented on the HIP path (1-D/3-D: SURVEY.md 8(f))")
+    if (conv_class, ndim) not in ((nn.Conv2d, 2), (nn.Conv1d, 1)):
+        raise NotImplementedError("the HIP path implements the 1-D and 2-D layers (3-D: SURVEY.md 8(f))")
+
+
+def _one(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 1:
+            raise ValueError(f"expected an int or a 1-tuple, got {v!r}")
+        return int(v[0])
+    return int(v)
 
 
 class _HipLayer(nn.Module):
+    """Shared plumbing.  1-D layers (ndim == 1) are lifted to 2-D: x [B,C,L] -> [B,C,1,L], weights [O,C,k] -> [O,C,1,k]
+    (views), kernel (1,k), stride (1,s), padding (0,p), dilation (1,d); InstanceNorm1d over L == InstanceNorm2d over 1 x L."""
+
     def _spec(self, **kw) -> ops.ConvSpec:
+        if getattr(self, "ndim", 2) == 1:
+            return ops.ConvSpec(kernel=(1, _one(self.kernel_size)), stride=(1, _one(self.stride)), padding=(0, _one(self.padding)),
+                                dilation=(1, _one(self.dilation)), groups=self.groups, **kw)
         return ops.ConvSpec(kernel=_pair(self.kernel_size), stride=_pair(self.stride), padding=_pair(self.padding),
                             dilation=_pair(self.dilation), groups=self.groups, **kw)
+
+    def _lift(self, x):
+        if getattr(self, "ndim", 2) == 1:
+            if x.dim() != 3:
+                raise ValueError(f"expected [B, C, L] input for a 1-D layer, got shape {tuple(x.shape)}")
+            return x.unsqueeze(2)
+        return x
+
+    def _lower(self, y):
+        return y.squeeze(2) if getattr(self, "ndim", 2) == 1 else y
+
+    def _w(self, convs):
+        return [m.weight.unsqueeze(2) for m in convs] if getattr(self, "ndim", 2) == 1 else [m.weight for m in convs]
 
     @staticmethod
     def _norm_affine(mods):
@@ -107,7 +138,7 @@ class KANConvNDLayer(_HipLayer):
         self.base_activation = base_activation() if base_activation is not None else nn.Identity()
         self.grid_range = grid_range
         self.norm_kwargs = norm_kwargs
-        self.dropout = _dropout2d(dropout)
+        self.dropout = _dropout2d(dropout, ndim)
         _check_groups(groups, input_dim, output_dim)
         self.input_dim_group, self.output_dim_group = input_dim // groups, output_dim // groups
 
@@ -135,20 +166,30 @@ class KANConvNDLayer(_HipLayer):
 
     def forward(self, x):
         spec = self.conv_spec()
-        wb = [m.weight for m in self.base_conv]
-        ws = [m.weight for m in self.spline_conv]
+        x = self._lift(x)
+        wb, ws = self._w(self.base_conv), self._w(self.spline_conv)
         prelus = [m.weight for m in self.prelus]
         if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
-            y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
+            y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
             # other norm classes (e.g. BatchNorm2d): HIP conv stage, then the caller's own norm module
-            z = ops.kan_conv(spec, x, None, wb, ws)
+            z = self._lower(ops.kan_conv(spec, x, None, wb, ws))
             og = self.output_dim_group
             y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
             y = self.dropout(y)
         return y
+
+
+class KANConv1DLayer(KANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, spline_order=3, groups=1, padding=0, stride=1, dilation=1,
+                 grid_size=5, base_activation=nn.GELU, grid_range=[-1, 1], dropout=0.0, norm_layer=nn.InstanceNorm1d,
+                 **norm_kwargs):
+        super().__init__(nn.Conv1d, norm_layer, input_dim, output_dim, spline_order, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=1,
+                         grid_size=grid_size, base_activation=base_activation, grid_range=grid_range, dropout=dropout,
+                         **norm_kwargs)
 
 
 class KANConv2DLayer(KANConvNDLayer):
@@ -191,7 +232,7 @@ class FastKANConvNDLayer(_HipLayer):
                                           for _ in range(groups)])
         self.layer_norm = nn.ModuleList([norm_class(cg, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
         self.rbf = RadialBasisFunction(grid_range[0], grid_range[1], grid_size)
-        self.dropout = _dropout2d(dropout)
+        self.dropout = _dropout2d(dropout, ndim)
         for conv in self.base_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.spline_conv:
@@ -213,10 +254,21 @@ class FastKANConvNDLayer(_HipLayer):
                 bet = torch.cat([m.bias for m in self.layer_norm])
             else:
                 gam = bet = None
-            xn = ops.instance_norm(xs, gam, bet, eps=self.layer_norm[0].eps)
+            xn = self._lift(xs) if xs.dim() == 3 else xs
+            xn = ops.instance_norm(xn.contiguous(), gam, bet, eps=self.layer_norm[0].eps)
         else:
-            xn = torch.cat([self.layer_norm[g](xs[:, g * cg:(g + 1) * cg]) for g in range(self.groups)], dim=1)
-        return ops.kan_conv(self.conv_spec(), x, xn, [m.weight for m in self.base_conv], [m.weight for m in self.spline_conv])
+            xn = self._lift(torch.cat([self.layer_norm[g](xs[:, g * cg:(g + 1) * cg]) for g in range(self.groups)], dim=1))
+        return self._lower(ops.kan_conv(self.conv_spec(), self._lift(x), xn, self._w(self.base_conv), self._w(self.spline_conv)))
+
+
+class FastKANConv1DLayer(FastKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, groups=1, padding=0, stride=1, dilation=1,
+                 grid_size=8, base_activation=nn.SiLU, grid_range=[-2, 2], dropout=0.0,
+                 norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(nn.Conv1d, norm_layer, input_dim, output_dim, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=1,
+                         grid_size=grid_size, base_activation=base_activation, grid_range=grid_range,
+                         dropout=dropout, **norm_kwargs)
 
 
 class FastKANConv2DLayer(FastKANConvNDLayer):
@@ -239,13 +291,13 @@ class ChebyKANConvNDLayer(_HipLayer):
         self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
         self.norm_kwargs = norm_kwargs
         self.epsilon = 1e-7
-        self.dropout = _dropout2d(dropout)
+        self.dropout = _dropout2d(dropout, ndim)
         _check_groups(groups, input_dim, output_dim)
         og = output_dim // groups
         self.layer_norm = nn.ModuleList([norm_layer(og, **_filter_norm_kwargs(norm_layer, norm_kwargs)) for _ in range(groups)])
         self.poly_conv = nn.ModuleList([conv_class((degree + 1) * input_dim // groups, og, kernel_size, stride, padding, dilation,
                                                    groups=1, bias=False) for _ in range(groups)])
-        self.register_buffer("arange", torch.arange(0, degree + 1, 1).view(1, 1, -1, 1, 1))
+        self.register_buffer("arange", torch.arange(0, degree + 1, 1).view(1, 1, -1, *([1] * ndim)))    # cheby_kan_layers.py:85-86
         for conv in self.poly_conv:
             # cheby_kan_layers.py:88-90 (normal_ first, then overwritten; `**` requires an int kernel_size, as there)
             nn.init.normal_(conv.weight, mean=0.0, std=1 / (input_dim * (degree + 1) * kernel_size ** ndim))
@@ -258,17 +310,25 @@ class ChebyKANConvNDLayer(_HipLayer):
 
     def forward(self, x):
         spec = self.conv_spec()
-        wp = [m.weight for m in self.poly_conv]
+        x = self._lift(x)
+        wp = self._w(self.poly_conv)
         if _fusable_instnorm(self.layer_norm):
             gam, bet = self._norm_affine(self.layer_norm)
-            y = ops.kan_conv_in_prelu(spec, x, [], wp, gam, bet, None, eps=self.layer_norm[0].eps)
+            y = self._lower(ops.kan_conv_in_prelu(spec, x, [], wp, gam, bet, None, eps=self.layer_norm[0].eps))
         else:
-            z = ops.kan_conv(spec, x, None, [], wp)
+            z = self._lower(ops.kan_conv(spec, x, None, [], wp))
             og = self.output_dim // self.groups
             y = torch.cat([self.layer_norm[g](z[:, g * og:(g + 1) * og]) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
             y = self.dropout(y)
         return y
+
+
+class ChebyKANConv1DLayer(ChebyKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree=3, groups=1, padding=0, stride=1, dilation=1,
+                 dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(nn.Conv1d, norm_layer, input_dim, output_dim, degree, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=1, dropout=dropout, **norm_kwargs)
 
 
 class ChebyKANConv2DLayer(ChebyKANConvNDLayer):
@@ -278,6 +338,6 @@ class ChebyKANConv2DLayer(ChebyKANConvNDLayer):
                          groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2, dropout=dropout, **norm_kwargs)
 
 
-__all__ = ["KANConvNDLayer", "KANConv2DLayer", "FastKANConvNDLayer", "FastKANConv2DLayer",
-           "ChebyKANConvNDLayer", "ChebyKANConv2DLayer", "RadialBasisFunction"]
+__all__ = ["KANConvNDLayer", "KANConv2DLayer", "KANConv1DLayer", "FastKANConvNDLayer", "FastKANConv2DLayer", "FastKANConv1DLayer",
+           "ChebyKANConvNDLayer", "ChebyKANConv2DLayer", "ChebyKANConv1DLayer", "RadialBasisFunction"]
 _ = F

@@ -29,7 +29,12 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
-from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm, _need_conv2d)
+from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm)
+
+
+def _need_conv2d(conv_class, ndim):
+    if conv_class is not nn.Conv2d or ndim != 2:
+        raise NotImplementedError("the polynomial-family layers are built for 2-D only (1-D/3-D: SURVEY.md 8(f))")
 
 Coeffs = Tuple[float, float, float, List[Tuple[float, float, float]]]       # c0, a1, b1, [(A_k, B_k, C_k) for k = 2..]
 

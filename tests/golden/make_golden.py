@@ -31,6 +31,7 @@ sys.dont_write_bytecode = True
 
 from layers import KANConv2DLayer, FastKANConv2DLayer, ChebyKANConv2DLayer  # noqa: E402  (reference)
 import layers as REF_LAYERS  # noqa: E402  (reference package)
+from layers import KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv1DLayer  # noqa: E402  (reference 1-D shims)
 from layers import KANLayer as RefKANLayer  # noqa: E402  (reference, layers/kan_layers.py:8-114)
 from oracle import kan_oracle as O  # noqa: E402
 
@@ -140,8 +141,21 @@ POLY_CASES += [
 ]
 
 
+# ---- 1-D shims of the three hot-path families (kan_layers.py:287-297 etc.): [B, C, L] inputs, H is ignored (ndim = 1)
+CASES_1D = [
+    C("bspline", "1d_tiny", 2, 3, 4, 1, 20, ndim=1),
+    C("bspline", "1d_s2g2_affine", 3, 4, 6, 1, 33, ndim=1, s=2, groups=2, act="silu", norm_kwargs={"affine": True}),
+    C("bspline", "1d_k5d2", 2, 5, 7, 1, 40, ndim=1, k=5, p=4, d=2, xs=2.0),
+    C("rbf", "1d_tiny", 2, 3, 4, 1, 20, ndim=1),
+    C("rbf", "1d_k5s2", 2, 4, 6, 1, 37, ndim=1, k=5, p=2, s=2),
+    C("cheby", "1d_tiny", 2, 3, 4, 1, 20, ndim=1),
+    C("cheby", "1d_deg4g2", 2, 4, 6, 1, 31, ndim=1, degree=4, groups=2, norm_kwargs={"affine": True}),
+]
+
+
 def build_ref(c):
     kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
+    one_d = c.get("ndim", 2) == 1
     if c["kind"] in POLY_FAMILIES:
         kw.update(c.get("norm_kwargs", {}))
         kw.update(c.get("extra", {}))
@@ -163,25 +177,40 @@ def build_ref(c):
                 kw[key] = c[key]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
-        return KANConv2DLayer(c["C"], c["O"], **kw)
+        return (KANConv1DLayer if one_d else KANConv2DLayer)(c["C"], c["O"], **kw)
     if c["kind"] == "rbf":
         for key in ("grid_size", "grid_range"):
             if key in c:
                 kw[key] = c[key]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
-        return FastKANConv2DLayer(c["C"], c["O"], **kw)
+        return (FastKANConv1DLayer if one_d else FastKANConv2DLayer)(c["C"], c["O"], **kw)
     if "degree" in c:
         kw["degree"] = c["degree"]
-    return ChebyKANConv2DLayer(c["C"], c["O"], **kw)
+    return (ChebyKANConv1DLayer if one_d else ChebyKANConv2DLayer)(c["C"], c["O"], **kw)
 
 
 def oracle_forward(c, layer, x, pre):
     """Run the oracle with the reference layer's parameters."""
-    sd = dict(layer.named_parameters())
+    if c.get("ndim", 2) == 1:
+        return oracle_forward_1d(c, layer, x, pre)
+    return oracle_forward_2d(c, layer, dict(layer.named_parameters()), [layer.layer_norm[g] for g in range(c["groups"])],
+                             dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=c["groups"]), x, pre)
+
+
+def oracle_forward_1d(c, layer, x, pre):
+    """1-D layer == the 2-D oracle on [B, C, 1, L] with (1, k) kernels; norms act on the squeezed tensor."""
+    sd = {n: p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
+    norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(c["groups"])]
+    geo = dict(stride=(1, c["s"]), padding=(0, c["p"]), dilation=(1, c["d"]), groups=c["groups"])
+    pre4 = []
+    y = oracle_forward_2d(c, layer, sd, norms, geo, x.unsqueeze(2), pre4)
+    pre.extend(p.squeeze(2) for p in pre4)
+    return y.squeeze(2)
+
+
+def oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
     G = c["groups"]
-    norms = [layer.layer_norm[g] for g in range(G)]
-    geo = dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=G)
     if c["kind"] == "bspline":
         act = ACT_FN[c.get("act", "gelu")]
         knots = O.bspline_knots(layer.grid_size, layer.spline_order, layer.grid_range)
@@ -234,10 +263,13 @@ def run_case(idx, c):
             elif p.dim() == 4:
                 fan_in = p.shape[1] * p.shape[2] * p.shape[3]
                 det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
+            elif p.dim() == 3 and c.get("ndim", 2) == 1:        # Conv1d weights [O, C, k]
+                det_fill(p, idx * 31 + j, (3.0 / (p.shape[1] * p.shape[2])) ** 0.5)
             elif p.dim() == 5:                                  # JacobiKAN poly_weights [G, O/G, C/G*(deg+1), k, k]
                 fan_in = p.shape[2] * p.shape[3] * p.shape[4]
                 det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
-    x = mk_input((c["B"], c["C"], c["H"], c["W"]), idx, c["xscale"]).requires_grad_(True)
+    shape = (c["B"], c["C"], c["W"]) if c.get("ndim", 2) == 1 else (c["B"], c["C"], c["H"], c["W"])
+    x = mk_input(shape, idx, c["xscale"]).requires_grad_(True)
 
     pre_ref = []
     hooks = []
@@ -395,6 +427,12 @@ def poly_cases():
         print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 
 
+def cases_1d():
+    for i, c in enumerate(CASES_1D):
+        worst, sz = run_case(len(CASES) + len(POLY_CASES) + i, c)
+        print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 def mlp_cases():
     for i, c in enumerate(MLP_CASES):
         worst, sz = run_mlp_case(i, c)
@@ -459,6 +497,8 @@ def main():
         return mlp_cases()
     if "--poly-only" in sys.argv:                   # regenerate just the polynomial-family fixtures
         return poly_cases()
+    if "--1d-only" in sys.argv:
+        return cases_1d()
     total = 0
     for i, c in enumerate(CASES):
         worst, sz = run_case(i, c)
@@ -467,6 +507,7 @@ def main():
     basis_probes()
     mlp_cases()
     poly_cases()
+    cases_1d()
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)

@@ -49,6 +49,9 @@ def build_layer(c):
     import convkan_amd as K
     if c["kind"] in POLY:
         return getattr(K, POLY[c["kind"]])(c["C"], c["O"], **layer_kwargs(c))
+    if c.get("ndim", 2) == 1:
+        cls = {"bspline": K.KANConv1DLayer, "rbf": K.FastKANConv1DLayer, "cheby": K.ChebyKANConv1DLayer}[c["kind"]]
+        return cls(c["C"], c["O"], **layer_kwargs(c))
     cls = {"bspline": K.KANConv2DLayer, "rbf": K.FastKANConv2DLayer, "cheby": K.ChebyKANConv2DLayer}[c["kind"]]
     return cls(c["C"], c["O"], **layer_kwargs(c))
 
@@ -60,11 +63,23 @@ def relerr(a, b):
 
 def oracle_forward(c, layer, x, pre=None):
     """Oracle forward with `layer`'s parameters (any object exposing the reference's attribute names)."""
+    G = c["groups"]
+    if c.get("ndim", 2) == 1:          # 1-D layer == the 2-D oracle on [B, C, 1, L] with (1, k) kernels
+        sd = {n: p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
+        norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(G)]
+        geo = dict(stride=(1, c["s"]), padding=(0, c["p"]), dilation=(1, c["d"]), groups=G)
+        pre4 = [] if pre is not None else None
+        y = _oracle_forward_2d(c, layer, sd, norms, geo, x.unsqueeze(2), pre4)
+        if pre is not None:
+            pre.extend(p.squeeze(2) for p in pre4)
+        return y.squeeze(2)
+    return _oracle_forward_2d(c, layer, dict(layer.named_parameters()), [layer.layer_norm[g] for g in range(G)],
+                              dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=G), x, pre)
+
+
+def _oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
     from oracle import kan_oracle as O
     G = c["groups"]
-    sd = dict(layer.named_parameters())
-    norms = [layer.layer_norm[g] for g in range(G)]
-    geo = dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=G)
     if c["kind"] == "bspline":
         knots = O.bspline_knots(layer.grid_size, layer.spline_order, layer.grid_range).to(x.device)
         return O.kan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"spline_conv.{g}.weight"] for g in range(G)],

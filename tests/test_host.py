@@ -116,6 +116,21 @@ def test_constructor_surface():
             cls(4, 3, 3, groups=2)
 
 
+def test_1d_shims_surface():
+    """kan_layers.py:287-297, fast_kan_layers.py:151-162, cheby_kan_layers.py:134-141: Conv1d weight holders, InstanceNorm1d."""
+    a = K.KANConv1DLayer(4, 6, 3, groups=2, padding=1)
+    assert a.ndim == 1 and isinstance(a.base_conv[0], nn.Conv1d) and isinstance(a.layer_norm[0], nn.InstanceNorm1d)
+    assert a.spline_conv[1].weight.shape == (3, 16, 3) and a.conv_spec().kernel == (1, 3) and a.conv_spec().padding == (0, 1)
+    f = K.FastKANConv1DLayer(3, 4, 5, stride=2, dropout=0.1)
+    assert isinstance(f.dropout, nn.Dropout1d) and f.conv_spec().stride == (1, 2) and list(f.state_dict())[-1] == "rbf.grid"
+    c = K.ChebyKANConv1DLayer(3, 4, 3, degree=4)
+    assert c.arange.shape == (1, 1, 5, 1) and list(c.state_dict()) == ["arange", "poly_conv.0.weight"]
+    with pytest.raises(NotImplementedError):
+        K.KANConvNDLayer(nn.Conv3d, nn.InstanceNorm3d, 3, 4, 3, 3, ndim=3)
+    with pytest.raises(Exception):
+        a(torch.zeros(2, 4, 8, 8))                                # a 1-D layer takes [B, C, L]
+
+
 def test_polynomial_family_surface():
     """State-dict keys, attributes and validation messages of the recurrence families (e.g. lucas_kan_layers.py:76-139)."""
     for cls in (K.BesselKANConv2DLayer, K.FibonacciKANConv2DLayer, K.HermiteKANConv2DLayer, K.LucasKANConv2DLayer, K.TaylorKANConv2DLayer):

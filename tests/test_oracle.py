@@ -31,7 +31,7 @@ class _Params(nn.Module):
         if "sd.poly_weights" in d:                                # JacobiKAN: one [G, O/G, C/G*(deg+1), k, k] parameter
             self.poly_weights = nn.Parameter(torch.from_numpy(d["sd.poly_weights"]))
             self.a, self.b = c.get("extra", {}).get("a"), c.get("extra", {}).get("b")
-        norm_cls = NORMS[c.get("norm", "in")]
+        norm_cls = NORMS[c.get("norm", "in")] if c.get("ndim", 2) == 2 else nn.InstanceNorm1d
         nch = (c["C"] if c["kind"] == "rbf" else c["O"]) // G
         kw = {k: v for k, v in c.get("norm_kwargs", {}).items()}
         self.layer_norm = nn.ModuleList([norm_cls(nch, **kw) for _ in range(G)])

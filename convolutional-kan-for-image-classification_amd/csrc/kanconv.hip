@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) void k_position_major(const float* __restrict_
 //   1 / 2 : B-spline grid 5, order 3 (8 bases) + base branch SiLU / GELU          P = 9   (KANConv2DLayer defaults)
 //   3     : RBF, 8 centres + base branch SiLU                                     P = 9   (FastKANConv2DLayer defaults)
 //   4 / 5 : Chebyshev degree 4 / 3, no base branch                                P = 5 / 4
-__host__ __device__ constexpr int fast_planes(int fast) { return fast == 4 ? 5 : fast == 5 ? 4 : 9; }
+__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6) ? 5 : (fast == 5 || fast == 7) ? 4 : 9; }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
 template <int KIND, int FAST>
@@ -305,6 +305,27 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
         for (int k = 1; k < fast_planes(FAST); ++k) {
             col[k * ld] = inb ? Tc : 0.f;
             const float Tn = 2.f * t * Tc - Tm; Tm = Tc; Tc = Tn;
+        }
+        return;
+    }
+    if (KIND == KAN_BASIS_POLY && (FAST == 6 || FAST == 7)) {
+        // Recurrence families with a base branch and 4 (FAST 6) or 3 (FAST 7) polynomial planes -- degree 3, the
+        // reference's default -- so P is a compile-time 5 / 4.  Activation and squash stay runtime (uniform branches),
+        // coefficients come from the kernel argument (scalar registers).  tanh through hardware exp2/rcp as above.
+        constexpr int NB = FAST == 6 ? 4 : 3;
+        const float base = bs.act == KAN_ACT_SILU ? silu_fast(xa) : kan_act(bs.act, xa);
+        float t = xb;
+        if (bs.order) {
+            const float e = __builtin_amdgcn_exp2f(fminf(xb, 40.f) * 2.88539008177792681472f);
+            t = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+        }
+        float Tm = bs.tab[0], Tc = bs.tab[1] * t + bs.tab[2];
+        col[0] = inb ? base : 0.f;
+        col[ld] = inb ? Tm : 0.f;
+#pragma unroll
+        for (int k = 1; k < NB; ++k) {
+            col[(1 + k) * ld] = inb ? Tc : 0.f;
+            if (k + 1 < NB) { const float Tn = (bs.tab[3 * k] * t + bs.tab[3 * k + 1]) * Tc + bs.tab[3 * k + 2] * Tm; Tm = Tc; Tc = Tn; }
         }
         return;
     }
@@ -712,6 +733,66 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const bool split_out = (dxn != nullptr);
     float* dxs = dx + (size_t)blockIdx.z * slab_elems;
     float* dxns = split_out ? dxn + (size_t)blockIdx.z * slab_elems : nullptr;
+    if (FAST == 6 || FAST == 7) {
+        // Recurrence families, degree 3 with a base branch (P = 5 / 4, CH = 12 / 16 channels per half), single input
+        // tensor: x prefetched, derivative by the differentiated recurrence with compile-time plane count.
+        constexpr int FP = FAST == 6 ? 5 : 4, NB = FP - 1, FCH = 64 / FP, NIT = (FCH + 1) / 2;
+        float xv[2][NIT]; unsigned ok = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const bool v = cl < FCH && c < g.C && pv;
+                xv[half][it] = v ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
+                ok |= (v ? 1u : 0u) << (half * NIT + it);
+            }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (w_r == half) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            smem[(mi * 32 + mfma_row(r, lane)) * TP + w_p * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!((ok >> (half * NIT + it)) & 1u)) continue;
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const float xa = half == 0 ? xv[0][it] : xv[1][it];
+                float dact;
+                if (bs.act == KAN_ACT_SILU) {
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xa * -1.44269504088896340736f));
+                    dact = sg * (1.0f + xa * (1.0f - sg));
+                } else dact = kan_act_grad(bs.act, xa);
+                float t = xa, chain = 1.0f;
+                if (bs.order) {
+                    const float e = __builtin_amdgcn_exp2f(fminf(xa, 40.f) * 2.88539008177792681472f);
+                    t = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+                    chain = 1.0f - t * t;
+                }
+                const float* G = smem + (cl * FP) * TP + pxl;
+                float Tm = bs.tab[0], Tc = bs.tab[1] * t + bs.tab[2], Dm = 0.f, Dc = bs.tab[1];
+                float sb = 0.f;                                        // sum_k T_k'(t) G_k   (T_0' = 0)
+#pragma unroll
+                for (int k = 1; k < NB; ++k) {
+                    sb += Dc * G[(1 + k) * TP];
+                    if (k + 1 < NB) {
+                        const float A = bs.tab[3 * k], B = bs.tab[3 * k + 1], Cc = bs.tab[3 * k + 2], sc = A * t + B;
+                        const float Tn = sc * Tc + Cc * Tm, Dn = A * Tc + sc * Dc + Cc * Dm;
+                        Tm = Tc; Tc = Tn; Dm = Dc; Dc = Dn;
+                    }
+                }
+                dxs[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] = dact * G[0] + sb * chain;
+            }
+        }
+        return;
+    }
     if (FAST != 0) {
         // Compile-time spec (B-spline grid 5 / order 3, P = 9, CH = 7; FAST 1: SiLU, 2: GELU), single input tensor.
         // All x values of this thread's (channel, pixel) pairs are fetched up front (the generic loop below pays one
@@ -1268,7 +1349,7 @@ int fast_variant(const KanBasis* b);
 bool big_tiles(const KanBasis* b, const KanPlan& pl) {
     static const int off = getenv("KAN_BIG") ? (atoi(getenv("KAN_BIG")) == 0) : 0;         // KAN_BIG=0: A/B switch (tuning only)
     const int f = fast_variant(b);
-    return !off && pl.Opad % 256 == 0 && (f == 1 || f == 2 || f == 4);
+    return !off && pl.Opad % 256 == 0 && (f == 1 || f == 2 || f == 4 || f == 6);
 }
 struct FwdCfg { int TO, TP, tiles_o, tiles_p, chunks, splits, slots; };
 FwdCfg fwd_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
@@ -1440,6 +1521,7 @@ int fast_variant(const KanBasis* b) {
     if (b->kind == KAN_BASIS_BSPLINE && b->n_basis == 8 && b->order == 3) return b->act == KAN_ACT_SILU ? 1 : b->act == KAN_ACT_GELU ? 2 : 0;
     if (b->kind == KAN_BASIS_RBF && b->n_basis == 8 && b->act == KAN_ACT_SILU) return 3;
     if (b->kind == KAN_BASIS_CHEBY && b->act == KAN_ACT_NONE) return b->n_basis == 5 ? 4 : b->n_basis == 4 ? 5 : 0;
+    if (b->kind == KAN_BASIS_POLY && b->act != KAN_ACT_NONE) return b->n_basis == 4 ? 6 : b->n_basis == 3 ? 7 : 0;
     return 0;
 }
 
@@ -1592,12 +1674,15 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     if (c.TO == 256 && fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 4, 2, 18);
     else if (c.TO == 256 && fast == 2) KAN_FWD2(KAN_BASIS_BSPLINE, 2, 4, 2, 18);
     else if (c.TO == 256 && fast == 4) KAN_FWD2(KAN_BASIS_CHEBY, 4, 4, 2, 16);
+    else if (c.TO == 256 && fast == 6) KAN_FWD2(KAN_BASIS_POLY, 6, 4, 2, 16);
     else if (c.TO == 256) return fail("internal: no 256-output forward kernel for this basis");
     else if (fast == 1) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 1, 18);
     else if (fast == 2) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 2, 18);
     else if (fast == 3) KAN_FWD_FAST(KAN_BASIS_RBF, 3, 18);
     else if (fast == 4) KAN_FWD_FAST(KAN_BASIS_CHEBY, 4, 16);
     else if (fast == 5) KAN_FWD_FAST(KAN_BASIS_CHEBY, 5, 16);
+    else if (fast == 6) KAN_FWD_FAST(KAN_BASIS_POLY, 6, 16);
+    else if (fast == 7) KAN_FWD_FAST(KAN_BASIS_POLY, 7, 16);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_FWD_KIND(KAN_BASIS_POLY);
@@ -1640,6 +1725,8 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     const int fast = (x == xn && !dxn) ? fast_variant(b) : 0;
     if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BD2(KAN_BASIS_BSPLINE, 2);
+    else if (fast == 6) KAN_BD2(KAN_BASIS_POLY, 6);
+    else if (fast == 7) KAN_BD2(KAN_BASIS_POLY, 7);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
@@ -1673,12 +1760,15 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     if (c.TO == 256 && fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 2, 4);
     else if (c.TO == 256 && fast == 2) KAN_BW2(KAN_BASIS_BSPLINE, 2, 2, 4);
     else if (c.TO == 256 && fast == 4) KAN_BW2(KAN_BASIS_CHEBY, 4, 2, 4);
+    else if (c.TO == 256 && fast == 6) KAN_BW2(KAN_BASIS_POLY, 6, 2, 4);
     else if (c.TO == 256) return fail("internal: no 256-output weight-gradient kernel for this basis");
     else if (fast == 1) KAN_BW_FAST(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BW_FAST(KAN_BASIS_BSPLINE, 2);
     else if (fast == 3) KAN_BW_FAST(KAN_BASIS_RBF, 3);
     else if (fast == 4) KAN_BW_FAST(KAN_BASIS_CHEBY, 4);
     else if (fast == 5) KAN_BW_FAST(KAN_BASIS_CHEBY, 5);
+    else if (fast == 6) KAN_BW_FAST(KAN_BASIS_POLY, 6);
+    else if (fast == 7) KAN_BW_FAST(KAN_BASIS_POLY, 7);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BW_KIND(KAN_BASIS_POLY);

@@ -733,6 +733,54 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const bool split_out = (dxn != nullptr);
     float* dxs = dx + (size_t)blockIdx.z * slab_elems;
     float* dxns = split_out ? dxn + (size_t)blockIdx.z * slab_elems : nullptr;
+    if (FAST == 4 || FAST == 5) {
+        // ChebyKAN degree 4 / 3 (P = 5 / 4 planes, no base branch): x prefetched, dT_k/dx = k U_{k-1}(t) (1 - tanh^2 x)
+        // inside the clamp, 0 where it is active (kan_device.h), tanh through hardware exp2/rcp as in the forward spec.
+        constexpr int FP = FAST == 4 ? 5 : 4, FCH = 64 / FP, NIT = (FCH + 1) / 2;
+        float xv[2][NIT]; unsigned ok = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const bool v = cl < FCH && c < g.C && pv;
+                xv[half][it] = v ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
+                ok |= (v ? 1u : 0u) << (half * NIT + it);
+            }
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (w_r == half) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            smem[(mi * 32 + mfma_row(r, lane)) * TP + w_p * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!((ok >> (half * NIT + it)) & 1u)) continue;
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const float xa = half == 0 ? xv[0][it] : xv[1][it];
+                const float e = __builtin_amdgcn_exp2f(fminf(xa, 40.f) * 2.88539008177792681472f);
+                const float t0 = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+                const float t = fminf(fmaxf(t0, bs.p0), bs.p1);
+                const float chain = (t0 >= bs.p0 && t0 <= bs.p1) ? (1.0f - t0 * t0) : 0.f;
+                const float* G = smem + (cl * FP) * TP + pxl;
+                float Um = 0.f, Uc = 1.f, sb = 0.f;
+#pragma unroll
+                for (int k = 1; k < FP; ++k) {
+                    sb += (float)k * Uc * G[k * TP];
+                    const float Un = 2.f * t * Uc - Um; Um = Uc; Uc = Un;
+                }
+                dxs[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] = sb * chain;
+            }
+        }
+        return;
+    }
     if (FAST == 6 || FAST == 7) {
         // Recurrence families, degree 3 with a base branch (P = 5 / 4, CH = 12 / 16 channels per half), single input
         // tensor: x prefetched, derivative by the differentiated recurrence with compile-time plane count.
@@ -1725,6 +1773,8 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     const int fast = (x == xn && !dxn) ? fast_variant(b) : 0;
     if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BD2(KAN_BASIS_BSPLINE, 2);
+    else if (fast == 4) KAN_BD2(KAN_BASIS_CHEBY, 4);
+    else if (fast == 5) KAN_BD2(KAN_BASIS_CHEBY, 5);
     else if (fast == 6) KAN_BD2(KAN_BASIS_POLY, 6);
     else if (fast == 7) KAN_BD2(KAN_BASIS_POLY, 7);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);

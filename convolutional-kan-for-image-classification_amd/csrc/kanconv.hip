@@ -998,6 +998,20 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         idx = g.pix_major ? (unsigned)((c * HW + hi * g.W + wi) * g.B + b) : (unsigned)(b * (int)g.xbs + c * HW + hi * g.W + wi);
         return pv && it >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
     };
+    // The units this thread gathers with register prefetch belong to FIXED items (the K loop walks pixels, the tile's
+    // rows stay): decode them once -- per step only the pixel part of the address changes.  (Was: an LDS read of the
+    // item table, three integer multiplies and the unpacking, per unit per step, all of it VALU = matrix time.)
+    int u_off[UPF], u_dr[UPF], u_dt[UPF]; unsigned u_ok = 0;
+    const int o_row0 = (o_tile0 + il0) * HoWo;                  // first dz row of this thread (elements)
+#pragma unroll
+    for (int u = 0; u < UPF; ++u) {
+        const int il = il0 + u * IPP;
+        const int it = il < n_items ? sItem[min(il, MAXI - 1)] : -1;
+        const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
+        u_dr[u] = r * g.dh; u_dt[u] = t * g.dw;
+        u_off[u] = (c * HW + u_dr[u] * g.W + u_dt[u]) * (g.pix_major ? g.B : 1);
+        u_ok |= (it >= 0 ? 1u : 0u) << u;
+    }
     auto issue = [&](int ch) {
         const int px = ch * KPX + pl;
         const bool pv = px < Mtot;
@@ -1015,19 +1029,19 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         }
         s_b = b; s_hi0 = ho * g.sh - g.ph; s_wi0 = wo * g.sw - g.pw; s_pv = pv;
         inb_mask = 0;
+        // pixel part of the gather address: image-major b*xbs + hi0*W + wi0, position-major (hi0*W + wi0)*B + b
+        const int px_off = g.pix_major ? (s_hi0 * g.W + s_wi0) * g.B + b : b * (int)g.xbs + s_hi0 * g.W + s_wi0;
 #pragma unroll
         for (int u = 0; u < UPF; ++u) {
-            const int il = il0 + u * IPP;
-            unsigned idx;
-            const bool inb = il < n_items && unit_addr(sItem[min(il, MAXI - 1)], b, s_hi0, s_wi0, pv, idx);
-            const unsigned off = inb ? idx * 4u : KAN_OOB;
+            const bool inb = pv && ((u_ok >> u) & 1u) && (unsigned)(s_hi0 + u_dr[u]) < (unsigned)g.H && (unsigned)(s_wi0 + u_dt[u]) < (unsigned)g.W;
+            const unsigned off = inb ? (unsigned)(px_off + u_off[u]) * 4u : KAN_OOB;
             xa[u] = buf_load(x_rs, off);
             xb[u] = same_in ? xa[u] : buf_load(xn_rs, off);
             inb_mask |= (inb ? 1u : 0u) << u;
         }
         const unsigned zbase = !pv ? KAN_OOB
-            : g.pix_major ? (((unsigned)(o_tile0 + il0) * (unsigned)HoWo + (unsigned)hw) * (unsigned)g.B + (unsigned)b) * 4u
-                          : ((unsigned)b * (unsigned)g.ybs + (unsigned)hw + (unsigned)(o_tile0 + il0) * (unsigned)HoWo) * 4u;
+            : g.pix_major ? ((unsigned)(o_row0 + hw) * (unsigned)g.B + (unsigned)b) * 4u
+                          : ((unsigned)b * (unsigned)g.ybs + (unsigned)(hw + o_row0)) * 4u;
         if (o_full) {                                          // uniform: the per-output part of the offset rides in a scalar
 #pragma unroll
             for (int n = 0; n < ZL; ++n)

@@ -60,12 +60,30 @@ int fail(const char* fmt, const char* a = "") {
     return -1;
 }
 
+// Division of a WAVE-UNIFORM non-negative int by a launch constant without the vector ALU.  hipcc expands `a / d` with
+// runtime d into ~20 VALU instructions (float reciprocal) even when a is uniform, and on gfx950 VALU issue slots are
+// matrix time (measured: each non-MFMA VALU per MFMA costs ~9 cycles of the 64-cycle MFMA).  q = (mulhi(a, m) + a) >> s
+// with the round-up magic m (Granlund-Montgomery; exact for 0 <= a < 2^31) is four scalar instructions.
+struct FastDiv { unsigned m; int s; };
+__host__ __device__ inline FastDiv make_fastdiv(int d) {
+    FastDiv f; f.s = 0;
+    while ((1ll << f.s) < d) ++f.s;                                   // s = ceil(log2 d)
+    f.m = (unsigned)((((1ull << f.s) - (unsigned long long)d) << 32) / (unsigned long long)d + 1ull);
+    return f;
+}
+__device__ __forceinline__ int fastdiv(int a, FastDiv f) {
+    if (f.s == 0) return a;                                           // d == 1 (uniform branch)
+    const unsigned t = __umulhi((unsigned)a, f.m);
+    return (int)((t + (((unsigned)a - t) >> 1)) >> (f.s - 1));
+}
+
 struct DevGeom {
     int B, C, H, W, O, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
     int howo_shift, wo_shift;    // log2(Ho*Wo), log2(Wo) when both are powers of two, else -1 (pixel decode by shifts)
     int pix_major;               // 1: GEMM pixel index = position*B + image (small planes: lets whole taps be skipped)
     int b_shift;                 // log2(B) or -1
     long long xbs, ybs;
+    FastDiv divC, divKw;         // by C and by kw (item -> tap, channel; tap -> r, t)
 };
 
 constexpr int PERM_MAX = 64;
@@ -473,8 +491,8 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;                                          // scalar
             const int item = ch * IPC + il;
-            const int tap = item / g.C, c = item - tap * g.C;                      // tap-major depth order
-            const int r = tap / g.kw, t = tap - r * g.kw;
+            const int tap = fastdiv(item, g.divC), c = item - tap * g.C;          // tap-major depth order (scalar division)
+            const int r = fastdiv(tap, g.divKw), t = tap - r * g.kw;
             const int dr = r * g.dh, dt = t * g.dw;
             const int hi = hi0 + dr, wi = wi0 + dt;
             const bool inb = il < IPC && pv && item < NI && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
@@ -1341,6 +1359,7 @@ DevGeom dev_geom(const KanGeom* g) {
     const int a = log2_exact(g->Ho * g->Wo), b = log2_exact(g->Wo);
     if (a >= 0 && b >= 0) { d.howo_shift = a; d.wo_shift = b; }
     d.b_shift = log2_exact(g->B);
+    d.divC = make_fastdiv(g->C); d.divKw = make_fastdiv(g->kw);
     return d;
 }
 // Position-major pixel order (and with it tap skipping) is offered on small padded planes (<= 16 positions: 31 % of

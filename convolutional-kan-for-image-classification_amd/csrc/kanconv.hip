@@ -355,11 +355,13 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
         if (live) {
             const int i = min((int)((xa - bs.g0) * bs.inv_h), 10);       // 11 knot intervals
             const float u = fminf(fmaxf((xa - sTab[i]) * bs.inv_h, 0.f), 1.f), v = 1.f - u;
-            const float u2 = u * u, u3 = u2 * u, k6 = 1.f / 6.f;
-            N0 = k6 * v * v * v;
-            N1 = k6 * (3.f * u3 - 6.f * u2 + 4.f);
-            N2 = k6 * (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f);
-            N3 = k6 * u3;
+            // two-wide (v_pk_*_f32): (N0, N3) = (v^3, u^3)/6 and, by the cubic's symmetry N1(u) = N2(1 - u),
+            // (N1, N2) = q(v), q(u) with q(t) = (-3t^3 + 3t^2 + 3t + 1)/6 in Horner form
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 vu = {v, u};
+            const f32x2 n03 = vu * vu * vu * (1.f / 6.f);
+            const f32x2 n12 = (((vu * -3.f + 3.f) * vu + 3.f) * vu + 1.f) * (1.f / 6.f);
+            N0 = n03.x; N3 = n03.y; N1 = n12.x; N2 = n12.y;
             j0 = i - 3;
         }
         col[0] = base;

@@ -296,18 +296,18 @@ __global__ __launch_bounds__(256) void k_position_major(const float* __restrict_
 //   1 / 2 : B-spline grid 5, order 3 (8 bases) + base branch SiLU / GELU          P = 9   (KANConv2DLayer defaults)
 //   3     : RBF, 8 centres + base branch SiLU                                     P = 9   (FastKANConv2DLayer defaults)
 //   4 / 5 : Chebyshev degree 4 / 3, no base branch                                P = 5 / 4
-__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6) ? 5 : (fast == 5 || fast == 7) ? 4 : 9; }
+__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6) ? 5 : (fast == 5 || fast == 7) ? 4 : fast == 8 ? 6 : 9; }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
 template <int KIND, int FAST>
 __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab, bool inb, float xa, float xb,
                                            float* col, int ld, float* dump) {
-    if (KIND == KAN_BASIS_RBF && FAST == 3) {
+    if (KIND == KAN_BASIS_RBF && (FAST == 3 || FAST == 8)) {          // 8 (FastKAN default) or 5 (grid_size 5, as kan_vgg.py builds it) centres
         // utils/utils.py:33 with hardware exp2: exp(-u^2) = exp2(-u^2 log2 e), u = (x - c_g) / d
         col[0] = inb ? silu_fast(xa) : 0.f;
         const float inv_d = 1.0f / bs.p0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < fast_planes(FAST) - 1; ++j) {
             const float u = (xb - bs.tab[j]) * inv_d;
             col[(1 + j) * ld] = inb ? __builtin_amdgcn_exp2f(u * u * -1.44269504088896340736f) : 0.f;
         }
@@ -1602,7 +1602,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
 // Compile-time specialisation available?  (numbers as documented at stage_unit; 0 = generic)
 int fast_variant(const KanBasis* b) {
     if (b->kind == KAN_BASIS_BSPLINE && b->n_basis == 8 && b->order == 3) return b->act == KAN_ACT_SILU ? 1 : b->act == KAN_ACT_GELU ? 2 : 0;
-    if (b->kind == KAN_BASIS_RBF && b->n_basis == 8 && b->act == KAN_ACT_SILU) return 3;
+    if (b->kind == KAN_BASIS_RBF && b->act == KAN_ACT_SILU && (b->n_basis == 8 || b->n_basis == 5)) return b->n_basis == 8 ? 3 : 8;
     if (b->kind == KAN_BASIS_CHEBY && b->act == KAN_ACT_NONE) return b->n_basis == 5 ? 4 : b->n_basis == 4 ? 5 : 0;
     if (b->kind == KAN_BASIS_POLY && b->act != KAN_ACT_NONE) return b->n_basis == 4 ? 6 : b->n_basis == 3 ? 7 : 0;
     return 0;
@@ -1762,6 +1762,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     else if (fast == 1) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 1, 18);
     else if (fast == 2) KAN_FWD_FAST(KAN_BASIS_BSPLINE, 2, 18);
     else if (fast == 3) KAN_FWD_FAST(KAN_BASIS_RBF, 3, 18);
+    else if (fast == 8) KAN_FWD_FAST(KAN_BASIS_RBF, 8, 18);
     else if (fast == 4) KAN_FWD_FAST(KAN_BASIS_CHEBY, 4, 16);
     else if (fast == 5) KAN_FWD_FAST(KAN_BASIS_CHEBY, 5, 16);
     else if (fast == 6) KAN_FWD_FAST(KAN_BASIS_POLY, 6, 16);
@@ -1850,6 +1851,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     else if (fast == 1) KAN_BW_FAST(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BW_FAST(KAN_BASIS_BSPLINE, 2);
     else if (fast == 3) KAN_BW_FAST(KAN_BASIS_RBF, 3);
+    else if (fast == 8) KAN_BW_FAST(KAN_BASIS_RBF, 8);
     else if (fast == 4) KAN_BW_FAST(KAN_BASIS_CHEBY, 4);
     else if (fast == 5) KAN_BW_FAST(KAN_BASIS_CHEBY, 5);
     else if (fast == 6) KAN_BW_FAST(KAN_BASIS_POLY, 6);

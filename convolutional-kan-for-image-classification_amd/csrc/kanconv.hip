@@ -753,6 +753,55 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const bool split_out = (dxn != nullptr);
     float* dxs = dx + (size_t)blockIdx.z * slab_elems;
     float* dxns = split_out ? dxn + (size_t)blockIdx.z * slab_elems : nullptr;
+    if (FAST == 3 || FAST == 8) {
+        // FastKAN (8 or 5 centres + SiLU base, P = 9 / 6), two inputs and two outputs: dx = SiLU'(x) G_0 on the raw
+        // tensor, dxn = sum_j (-2 u_j / d) exp(-u_j^2) G_{1+j} on the normalised one (utils/utils.py:33); both inputs
+        // prefetched, hardware exp2.
+        constexpr int FP = FAST == 3 ? 9 : 6, FCH = 64 / FP, NIT = (FCH + 1) / 2;
+        const float inv_d = 1.0f / bs.p0;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            float xv[NIT], nv[NIT]; unsigned ok = 0;       // this half's inputs, requested before the LDS round trip
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const bool v = cl < FCH && c < g.C && pv;
+                const size_t idx = (size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_);
+                xv[it] = v ? x[idx] : 0.f;
+                nv[it] = v ? xn[idx] : 0.f;
+                ok |= (v ? 1u : 0u) << it;
+            }
+            __syncthreads();
+            if (w_r == half) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            smem[(mi * 32 + mfma_row(r, lane)) * TP + w_p * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (!((ok >> it) & 1u)) continue;
+                const int cl = ol0 + 2 * it, c = (ct * 2 + half) * FCH + cl;
+                const float xa = xv[it], xb = nv[it];
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(xa * -1.44269504088896340736f));
+                const float* G = smem + (cl * FP) * TP + pxl;
+                float sb = 0.f;
+#pragma unroll
+                for (int j = 0; j < FP - 1; ++j) {
+                    const float u = (xb - bs.tab[j]) * inv_d;
+                    sb += u * __builtin_amdgcn_exp2f(u * u * -1.44269504088896340736f) * G[(1 + j) * TP];
+                }
+                const size_t idx = (size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_);
+                dxs[idx] = sg * (1.0f + xa * (1.0f - sg)) * G[0];
+                dxns[idx] = sb * (-2.0f * inv_d);
+            }
+        }
+        return;
+    }
     if (FAST == 4 || FAST == 5) {
         // ChebyKAN degree 4 / 3 (P = 5 / 4 planes, no base branch): x prefetched, dT_k/dx = k U_{k-1}(t) (1 - tanh^2 x)
         // inside the clamp, 0 where it is active (kan_device.h), tanh through hardware exp2/rcp as in the forward spec.
@@ -1806,9 +1855,13 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
 #define KAN_BD(KIND) KAN_BD2(KIND, 0)
 #define KAN_BD2(KIND, FAST) \
     hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
-    const int fast = (x == xn && !dxn) ? fast_variant(b) : 0;
+    // compile-time epilogues: single-input specs need x == xn and one output; the FastKAN specs need both tensors
+    const int fv = fast_variant(b);
+    const int fast = (fv == 3 || fv == 8) ? ((x != xn && dxn) ? fv : 0) : ((x == xn && !dxn) ? fv : 0);
     if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BD2(KAN_BASIS_BSPLINE, 2);
+    else if (fast == 3) KAN_BD2(KAN_BASIS_RBF, 3);
+    else if (fast == 8) KAN_BD2(KAN_BASIS_RBF, 8);
     else if (fast == 4) KAN_BD2(KAN_BASIS_CHEBY, 4);
     else if (fast == 5) KAN_BD2(KAN_BASIS_CHEBY, 5);
     else if (fast == 6) KAN_BD2(KAN_BASIS_POLY, 6);

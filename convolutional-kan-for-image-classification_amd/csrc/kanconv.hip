@@ -89,6 +89,23 @@ struct DevGeom {
 constexpr int PERM_MAX = 64;
 struct TilePerm { int n; unsigned short idx[PERM_MAX]; };          // pixel-tile dispatch order (n == 0: identity), see balance_tiles
 
+// XCD-aware block order.  Workgroups go to the 8 XCDs (each with its own L2) round-robin by linear block id, so with the
+// plain (x = pixel/row tile, y, z = split) order every XCD sees every split and pulls every byte of the streamed operand
+// (weights; or x / dz for the weight gradient) into its own L2: 8 copies from HBM / Infinity Cache.  Re-numbering the
+// blocks so that XCD j works through the j-th contiguous eighth of the (z, y, x) order keeps the blocks that stream the
+// SAME split on the SAME XCD, in step with each other.  `on` is false for position-major launches (own order).
+struct BlockId { int x, y, z; };
+__device__ __forceinline__ BlockId xcd_block_order(bool on) {
+    BlockId b{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const unsigned gx = gridDim.x, gy = gridDim.y, T = gx * gy * gridDim.z;
+    if (!on || (T & 7u)) return b;
+    const unsigned lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const unsigned logical = (lin >> 3) + (lin & 7u) * (T >> 3);
+    const unsigned r = logical / gx;
+    b.x = (int)(logical - r * gx); b.z = (int)(r / gy); b.y = (int)(r - (unsigned)b.z * gy);
+    return b;
+}
+
 // Structural zeros.  With zero padding, tap (r,t) of output position (ho,wo) reads outside the image for a fixed set
 // of positions; on 4x4 / 2x2 planes that is 31 % / 56 % of all (position, tap) products.  When the pixel axis is
 // ordered position-major, a 128-pixel tile holds one or two positions, so a tap is dead or alive for the WHOLE tile and
@@ -452,8 +469,9 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
     const int w_o = wave / WP, w_p = wave % WP;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
-    const int grp = blockIdx.y / tiles_o;                 // groups are folded into grid.y (scalar; 0 for ungrouped layers)
-    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, o_tile0 = (blockIdx.y - grp * tiles_o) * TO;
+    const BlockId blk = xcd_block_order(!g.pix_major);
+    const int grp = blk.y / tiles_o;                      // groups are folded into grid.y (scalar; 0 for ungrouped layers)
+    const int px_tile0 = (perm.n ? (int)perm.idx[blk.x] : blk.x) * TP, o_tile0 = (blk.y - grp * tiles_o) * TO;
     const int pxl = (wave % (TP / 64)) * 64 + lane, il0 = wave / (TP / 64);
     {   // group grp owns channels [grp*C, (grp+1)*C) of x / xn (NCHW, or the [C*H*W][B] copy), [grp*O, ..) of z, and its own packed block
         const size_t xo = (size_t)grp * g.C * HW * (g.pix_major ? g.B : 1);
@@ -531,7 +549,7 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    int ch0 = blockIdx.z * chunks_per_split;
+    int ch0 = blk.z * chunks_per_split;
     int ch1 = min(n_chunks, ch0 + chunks_per_split);
     // taps that are alive for at least one pixel position of this tile (all of them unless the tile is position-major)
     unsigned tapmask = 0xffffffffu;
@@ -545,10 +563,10 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
         // this tile's own split count: ~chunks_per_split live steps each; surplus workgroups only store a zero slab
         const int L = live_step_count(tapmask, T, n_chunks, seg);
         const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));
-        if ((int)blockIdx.z >= S) { ch0 = ch1 = n_chunks; }
+        if (blk.z >= S) { ch0 = ch1 = n_chunks; }
         else {
-            ch0 = blockIdx.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blockIdx.z / S), seg);
-            ch1 = (int)blockIdx.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blockIdx.z + 1) / S), seg);
+            ch0 = blk.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blk.z / S), seg);
+            ch1 = blk.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blk.z + 1) / S), seg);
         }
     }
     // first step >= ch that touches a live tap (a step holds IPC consecutive items of the tap-major depth axis)
@@ -586,7 +604,7 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
     }
 
     // ---- store: column (lane) = pixel => coalesced along the plane
-    float* zs = z + (size_t)blockIdx.z * slab_elems;
+    float* zs = z + (size_t)blk.z * slab_elems;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int px = px_tile0 + w_p * 64 + ni * 32 + (lane & 31);
@@ -625,8 +643,11 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const int w_r = wave >> 1, w_p = wave & 1;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, P = bs.P;
     const int Min = g.B * HW;
-    const int grp = blockIdx.y / n_ct;                    // groups are folded into grid.y
-    const int px_tile0 = (perm.n ? (int)perm.idx[blockIdx.x] : (int)blockIdx.x) * TP, ct = blockIdx.y - grp * n_ct;
+    // (plain order here: an XCD then holds a few pixel tiles for ALL channel tiles, which share the dz tile; grouping by
+    // split instead re-read dz once per channel tile -- measured 2.8x the fetch traffic)
+    const BlockId blk = xcd_block_order(false);
+    const int grp = blk.y / n_ct;                         // groups are folded into grid.y
+    const int px_tile0 = (perm.n ? (int)perm.idx[blk.x] : blk.x) * TP, ct = blk.y - grp * n_ct;
     const int ncol = n_ct * 128;
     const int pxl = (wave & 1) * 64 + lane, ol0 = wave >> 1;
     {
@@ -707,7 +728,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    int ch0 = blockIdx.z * chunks_per_split;
+    int ch0 = blk.z * chunks_per_split;
     int ch1 = min(n_chunks, ch0 + chunks_per_split);
     unsigned tapmask = 0xffffffffu;                        // taps alive for some pixel position of this tile
     if (g.pix_major) {
@@ -719,10 +740,10 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         auto seg = [&](int tap) { return tap * n_ob; };     // steps are (tap, output block)
         const int L = live_step_count(tapmask, T, n_chunks, seg);
         const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));   // ~chunks_per_split live steps each
-        if ((int)blockIdx.z >= S) { ch0 = ch1 = n_chunks; }
+        if (blk.z >= S) { ch0 = ch1 = n_chunks; }
         else {
-            ch0 = blockIdx.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blockIdx.z / S), seg);
-            ch1 = (int)blockIdx.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blockIdx.z + 1) / S), seg);
+            ch0 = blk.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blk.z / S), seg);
+            ch1 = blk.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blk.z + 1) / S), seg);
         }
     }
     auto next_live = [&](int ch) -> int {                  // steps are (tap, output block): skip dead taps whole
@@ -751,8 +772,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     // ---- epilogue: per 64-row half, G -> LDS, contract the P planes of each channel with plane'(x)
     const bool same_in = (x == xn);
     const bool split_out = (dxn != nullptr);
-    float* dxs = dx + (size_t)blockIdx.z * slab_elems;
-    float* dxns = split_out ? dxn + (size_t)blockIdx.z * slab_elems : nullptr;
+    float* dxs = dx + (size_t)blk.z * slab_elems;
+    float* dxns = split_out ? dxn + (size_t)blk.z * slab_elems : nullptr;
     if (FAST == 3 || FAST == 8) {
         // FastKAN (8 or 5 centres + SiLU base, P = 9 / 6), two inputs and two outputs: dx = SiLU'(x) G_0 on the raw
         // tensor, dxn = sum_j (-2 u_j / d) exp(-u_j^2) G_{1+j} on the normalised one (utils/utils.py:33); both inputs
@@ -1030,8 +1051,9 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
     const int w_r = wave / WC, w_c = wave % WC;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw, P = FAST ? fast_planes(FAST) : bs.P;
     const int Mtot = g.B * HoWo, NI = g.C * T;
-    const int grp = blockIdx.y / tiles_o;                 // groups are folded into grid.y
-    const int k0 = blockIdx.x * TR, o_tile0 = (blockIdx.y - grp * tiles_o) * TO;
+    const BlockId blk = xcd_block_order(!g.pix_major);
+    const int grp = blk.y / tiles_o;                      // groups are folded into grid.y
+    const int k0 = blk.x * TR, o_tile0 = (blk.y - grp * tiles_o) * TO;
     {
         const int es = g.pix_major ? g.B : 1;
         const size_t xo = (size_t)grp * g.C * HW * es;
@@ -1154,7 +1176,7 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    int ch0 = blockIdx.z * chunks_per_split;
+    int ch0 = blk.z * chunks_per_split;
     int ch1 = min(n_chunks, ch0 + chunks_per_split);
     // positions whose pixels give this row tile a non-zero contribution: a row tile spans one or two taps of the
     // tap-major depth axis, and a tap is structurally zero at some output positions (position-major steps only)
@@ -1167,10 +1189,10 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         auto seg = [&](int hw) { return (hw * g.B + KPX - 1) / KPX; };   // segment = position: its first whole step
         const int L = live_step_count(hwmask, HoWo, n_chunks, seg);
         const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));   // ~chunks_per_split live steps each
-        if ((int)blockIdx.z >= S) { ch0 = ch1 = n_chunks; }
+        if (blk.z >= S) { ch0 = ch1 = n_chunks; }
         else {
-            ch0 = blockIdx.z == 0 ? 0 : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * blockIdx.z / S), seg);
-            ch1 = (int)blockIdx.z == S - 1 ? n_chunks : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * (blockIdx.z + 1) / S), seg);
+            ch0 = blk.z == 0 ? 0 : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * blk.z / S), seg);
+            ch1 = blk.z == S - 1 ? n_chunks : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * (blk.z + 1) / S), seg);
         }
     }
     auto next_live = [&](int ch) -> int {
@@ -1196,7 +1218,7 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         KAN_MFMA_STEP(KPX / 2, ae, LDE, az, LDZ);
     }
 
-    float* out = dwp + (size_t)blockIdx.z * slab_elems;
+    float* out = dwp + (size_t)blk.z * slab_elems;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

@@ -58,6 +58,8 @@ class BucketedGradReducer:
             for i, p in enumerate(b.params):
                 self._where[p] = (b, i)
         self.cuda = bool(plist) and plist[0].is_cuda
+        # RCCL averages in the collective itself (ReduceOp.AVG); gloo (CPU tests) sums and the mean is taken afterwards
+        self.avg_in_collective = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
         self.side = torch.cuda.Stream(device=plist[0].device) if self.cuda else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in plist]
 
@@ -75,7 +77,8 @@ class BucketedGradReducer:
         if self.cuda:
             self.side.wait_stream(torch.cuda.current_stream(b.flat.device))
             with torch.cuda.stream(self.side):
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM,
+                                         group=self.group, async_op=True)
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -91,7 +94,7 @@ class BucketedGradReducer:
             if b.work is not None:
                 b.work.wait()                       # on CUDA: makes the CURRENT stream wait for the collective
                 b.work = None
-            if self.world > 1:
+            if self.world > 1 and not (self.avg_in_collective and self.cuda):
                 b.flat.mul_(1.0 / self.world)
             for v, p in zip(b.views, b.params):
                 if p.grad is not None:

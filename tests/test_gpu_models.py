@@ -77,3 +77,30 @@ def test_cheby_alexnet(gpu_lib):
     from convkan_amd.models import alexnet_kan
     torch.manual_seed(0)
     run("cheby_alexnet", alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4))
+
+
+def test_training_step_is_bitwise_deterministic(gpu_lib):
+    """Split-K slabs are summed in a fixed order and no float atomics touch the data path (only the PReLU-slope and
+    affine-norm gradients use atomics): two identical KAN-VGG11 steps must give bit-identical logits, input gradient and
+    conv-weight gradients.  Doubles as a race detector for the LDS-DMA pipelines (a wave reading a tile another wave's
+    async copy has not finished shows up here as run-to-run differences)."""
+    import torch.nn.functional as F
+    from convkan_amd.models import vggkan
+    torch.manual_seed(11)
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", dropout_linear=0.0).cuda().train()
+    x = torch.randn(256, 3, 32, 32, device="cuda")
+    t = torch.randint(0, 10, (256,), device="cuda")
+    runs = []
+    for _ in range(3):
+        m.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        logits = m(xi)
+        F.cross_entropy(logits, t).backward()
+        torch.cuda.synchronize()
+        runs.append((logits.detach().clone(), xi.grad.clone(),
+                     {n: p.grad.clone() for n, p in m.named_parameters() if p.dim() == 4}))
+    for k in (1, 2):
+        assert torch.equal(runs[0][0], runs[k][0]), "logits differ between identical runs"
+        assert torch.equal(runs[0][1], runs[k][1]), "input gradient differs between identical runs"
+        for n, g in runs[0][2].items():
+            assert torch.equal(g, runs[k][2][n]), f"{n} gradient differs between identical runs"

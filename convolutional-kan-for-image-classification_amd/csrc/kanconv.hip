@@ -1233,6 +1233,152 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         }
 }
 
+// ============================================================================ depthwise (one input channel per group)
+// With C = 1 and O <= 2 per group (kan_mobilenetv2.py:253-255 replace_depthwise) the GEMM tiles above run at 1/128
+// utilisation; these direct kernels do the same arithmetic per output element instead.  They are HBM / VALU bound
+// (T*P multiply-adds per element), read the SAME packed weights (wp: row k(tap, p), column o, one block per group) and
+// write the same slab layouts, so nothing else in the pipeline changes.  One block = 256 elements of one group.
+constexpr int DW_MAX_TP = 96;                      // taps * planes held in registers by the weight-gradient kernel
+
+__device__ __forceinline__ int dw_krow(int tap, int p, int IPC, int KC, int P) {   // packed row of (item = tap, plane p) when C == 1
+    const int chunk = tap / IPC;
+    return chunk * KC + (tap - chunk * IPC) * P + p;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_dw_fwd(const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wp,
+                                                float* __restrict__ z, DevGeom g, DevBasis bs, int Opad, int IPC, int KC, int Kpad) {
+    __shared__ float sTab[KAN_MAX_TABLE];
+    __shared__ float sWt[DW_MAX_TP * 2];             // [tap*P + p][o]
+    const int grp = blockIdx.y, T = g.kh * g.kw, P = bs.P, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    if (threadIdx.x < KAN_MAX_TABLE) sTab[threadIdx.x] = bs.tab[threadIdx.x];
+    for (int i = threadIdx.x; i < T * P * g.O; i += 256) {
+        const int o = i % g.O, tp = i / g.O, tap = tp / P, p = tp - tap * P;
+        sWt[tp * 2 + o] = wp[((size_t)grp * Kpad + dw_krow(tap, p, IPC, KC, P)) * Opad + o];
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.B * HoWo) return;
+    const int b = e / HoWo, hw = e - b * HoWo, ho = hw / g.Wo, wo = hw - ho * g.Wo;
+    const size_t xbase = (size_t)b * g.xbs + (size_t)grp * HW;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int tap = 0; tap < T; ++tap) {
+        const int r = tap / g.kw, t = tap - r * g.kw;
+        const int hi = ho * g.sh - g.ph + r * g.dh, wi = wo * g.sw - g.pw + t * g.dw;
+        if ((unsigned)hi >= (unsigned)g.H || (unsigned)wi >= (unsigned)g.W) continue;      // zero padding of the expanded operand
+        const float xa = x[xbase + hi * g.W + wi], xb = xn[xbase + hi * g.W + wi];
+        float v[KAN_PMAX];
+        kan_planes<KIND, false>(bs, sTab, xa, xb, v);
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p)
+            if (p < P) { acc0 += v[p] * sWt[(tap * P + p) * 2]; acc1 += v[p] * sWt[(tap * P + p) * 2 + 1]; }
+    }
+    float* zb = z + (size_t)b * g.ybs + (size_t)grp * g.O * HoWo + hw;
+    zb[0] = acc0;
+    if (g.O > 1) zb[HoWo] = acc1;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_dw_bwd_data(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn,
+                                                     const float* __restrict__ wp, float* __restrict__ dx, float* __restrict__ dxn,
+                                                     DevGeom g, DevBasis bs, int Opad, int IPC, int KC, int Kpad) {
+    __shared__ float sTab[KAN_MAX_TABLE];
+    __shared__ float sWt[DW_MAX_TP * 2];
+    const int grp = blockIdx.y, T = g.kh * g.kw, P = bs.P, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    if (threadIdx.x < KAN_MAX_TABLE) sTab[threadIdx.x] = bs.tab[threadIdx.x];
+    for (int i = threadIdx.x; i < T * P * g.O; i += 256) {
+        const int o = i % g.O, tp = i / g.O, tap = tp / P, p = tp - tap * P;
+        sWt[tp * 2 + o] = wp[((size_t)grp * Kpad + dw_krow(tap, p, IPC, KC, P)) * Opad + o];
+    }
+    __syncthreads();
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.B * HW) return;
+    const int b = e / HW, hw = e - b * HW, h = hw / g.W, w = hw - h * g.W;
+    const size_t xi = (size_t)b * g.xbs + (size_t)grp * HW + hw;
+    float G[KAN_PMAX];
+#pragma unroll
+    for (int p = 0; p < KAN_PMAX; ++p) G[p] = 0.f;
+    for (int tap = 0; tap < T; ++tap) {
+        const int r = tap / g.kw, t = tap - r * g.kw;
+        const int hn = h + g.ph - r * g.dh, wn = w + g.pw - t * g.dw;
+        if (hn < 0 || wn < 0) continue;
+        const int ho = hn / g.sh, wo = wn / g.sw;
+        if (ho * g.sh != hn || wo * g.sw != wn || ho >= g.Ho || wo >= g.Wo) continue;
+        const float* zb = dz + (size_t)b * g.ybs + (size_t)grp * g.O * HoWo + ho * g.Wo + wo;
+        const float d0 = zb[0], d1 = g.O > 1 ? zb[HoWo] : 0.f;
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p)
+            if (p < P) G[p] += d0 * sWt[(tap * P + p) * 2] + d1 * sWt[(tap * P + p) * 2 + 1];
+    }
+    float d[KAN_PMAX];
+    kan_planes<KIND, true>(bs, sTab, x[xi], xn[xi], d);
+    float s_base = 0.f, s_bas = 0.f;
+#pragma unroll
+    for (int p = 0; p < KAN_PMAX; ++p)
+        if (p < P) { if (p < bs.hb) s_base += d[p] * G[p]; else s_bas += d[p] * G[p]; }
+    if (dxn) { dx[xi] = s_base; dxn[xi] = s_bas; }
+    else dx[xi] = s_base + s_bas;
+}
+
+// Weight gradient: block (chunk, group) walks its share of the group's B*Ho*Wo pixels with one accumulator per (tap, plane)
+// in registers (statically indexed: T <= 9, planes padded to KAN_PMAX), one output of the group after the other, reduces
+// them over the block in a fixed order and writes slab `chunk`.
+constexpr int DW_T = 9;
+template <int KIND>
+__global__ __launch_bounds__(256) void k_dw_bwd_weight(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn,
+                                                       float* __restrict__ dwp, DevGeom g, DevBasis bs, int Krows, int Opad,
+                                                       long long slab_elems) {
+    __shared__ float sTab[KAN_MAX_TABLE];
+    __shared__ float sRed[4][DW_T * KAN_PMAX];
+    const int grp = blockIdx.y, T = g.kh * g.kw, P = bs.P, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < KAN_MAX_TABLE) sTab[threadIdx.x] = bs.tab[threadIdx.x];
+    __syncthreads();
+    float* out = dwp + (size_t)blockIdx.x * slab_elems + (size_t)grp * Krows * Opad;
+    const int total = g.B * HoWo;
+    for (int o = 0; o < g.O; ++o) {
+        float acc[DW_T][KAN_PMAX];
+#pragma unroll
+        for (int a = 0; a < DW_T; ++a)
+#pragma unroll
+            for (int p = 0; p < KAN_PMAX; ++p) acc[a][p] = 0.f;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            const int b = e / HoWo, hw = e - b * HoWo, ho = hw / g.Wo, wo = hw - ho * g.Wo;
+            const float dzv = dz[(size_t)b * g.ybs + (size_t)(grp * g.O + o) * HoWo + hw];
+            const size_t xbase = (size_t)b * g.xbs + (size_t)grp * HW;
+#pragma unroll
+            for (int tap = 0; tap < DW_T; ++tap) {
+                if (tap < T) {
+                    const int r = tap / g.kw, t = tap - r * g.kw;
+                    const int hi = ho * g.sh - g.ph + r * g.dh, wi = wo * g.sw - g.pw + t * g.dw;
+                    if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
+                        float v[KAN_PMAX];
+                        kan_planes<KIND, false>(bs, sTab, x[xbase + hi * g.W + wi], xn[xbase + hi * g.W + wi], v);
+#pragma unroll
+                        for (int p = 0; p < KAN_PMAX; ++p) acc[tap][p] += v[p] * dzv;      // planes >= P are zero
+                    }
+                }
+            }
+        }
+        // block reduction, fixed order: lanes by xor-shuffle, then the four waves through LDS
+#pragma unroll
+        for (int a = 0; a < DW_T; ++a)
+#pragma unroll
+            for (int p = 0; p < KAN_PMAX; ++p) {
+                float v = acc[a][p];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                if (lane == 0) sRed[wave][a * KAN_PMAX + p] = v;
+            }
+        __syncthreads();
+        for (int i = threadIdx.x; i < T * P; i += 256) {
+            const int tap = i / P, p = i - tap * P, q = tap * KAN_PMAX + p;
+            out[(size_t)i * Opad + o] = (sRed[0][q] + sRed[1][q]) + (sRed[2][q] + sRed[3][q]);
+        }
+        __syncthreads();
+    }
+}
+
 // ============================================================================ slab reduce
 __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ slabs, int n_slabs, long long slab_elems,
                                                      float* __restrict__ out, int Cn, int HW, long long bstride, long long total) {
@@ -1621,6 +1767,21 @@ BwCfg bw_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     return c;
 }
 
+// Depthwise groups (one input channel, <= 2 outputs per group, <= 9 taps): direct kernels instead of GEMM tiles.
+bool dw_direct(const KanGeom* g, const KanBasis* b) {
+    static const int off = getenv("KAN_DW") ? (atoi(getenv("KAN_DW")) == 0) : 0;           // KAN_DW=0: A/B switch (tuning only)
+    const int T = g->kh * g->kw, P = b->n_basis + (b->act != KAN_ACT_NONE);
+    return !off && g->C == 1 && g->O <= 2 && T <= DW_T && T * P <= DW_MAX_TP;
+}
+int dw_weight_chunks(const KanGeom* g) {           // slabs of the depthwise weight gradient: ~2048 blocks over all groups
+    const long long total = (long long)g->B * g->Ho * g->Wo;
+    int s = ceil_div(2048, ngroups(g));
+    const int most = ceil_div(total, 256);
+    if (s > most) s = most;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+
 int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     if (int rc = check(g, b)) return rc;
     const int T = g->kh * g->kw;
@@ -1649,6 +1810,13 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
+    if (dw_direct(g, b)) {                          // direct depthwise kernels: no split-K on the data path, no position-major copies
+        pl->fwd_splits = pl->bwd_data_splits = 1;
+        pl->bwd_weight_splits = dw_weight_chunks(g);
+        pl->x_pm_wanted = pl->dz_pm_wanted = 0;
+        pl->bwd_data_weight_bytes = pl->packed_weight_bytes;      // the direct bwd-data kernel reads the forward layout: wd = copy of wp
+        return 0;
+    }
     if (want_pix_major(g, b, PM_FWD)) {          // forward: one class per output position; a tap holds C/IPC steps
         LiveClass cls[16]; const int plane = g->Ho * g->Wo; FwdCfg fc = fwd_cfg(g, b, *pl);
         const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o * G;
@@ -1750,7 +1918,9 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
     }
     dim3 grid(ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32, G);
     hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_basis, wp, q, 1, wp_gs);
-    if (wd) {
+    if (wd && dw_direct(g, b)) {
+        if (hipMemcpyAsync(wd, wp, (size_t)pl.packed_weight_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("memcpy failed");
+    } else if (wd) {
         BdCfg c = bd_cfg(g, pl);
         if ((long long)(c.Opad32 / 32) * G > 65535) return fail("groups * output blocks exceed the grid limit");
         dim3 gd(c.tiles_c * 4, c.Opad32 / 32 * G, T);
@@ -1795,6 +1965,20 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!x || !xn || !wp || !z) return fail("null tensor pointer");
+    if (dw_direct(g, b)) {
+        DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
+        dim3 grid(ceil_div((long long)g->B * g->Ho * g->Wo, 256), ngroups(g));
+#define KAN_DWF(KIND) hipLaunchKernelGGL((k_dw_fwd<KIND>), grid, dim3(256), 0, (hipStream_t)stream, x, xn, wp, z, dgd, dbd, pl.Opad, pl.IPC, pl.KC, pl.Kpad)
+        switch (b->kind) {
+            case KAN_BASIS_BSPLINE: KAN_DWF(KAN_BASIS_BSPLINE); break;
+            case KAN_BASIS_RBF: KAN_DWF(KAN_BASIS_RBF); break;
+            case KAN_BASIS_POLY: KAN_DWF(KAN_BASIS_POLY); break;
+            case KAN_BASIS_FOURIER: KAN_DWF(KAN_BASIS_FOURIER); break;
+            default: KAN_DWF(KAN_BASIS_CHEBY); break;
+        }
+#undef KAN_DWF
+        return launch_ok("dw_fwd");
+    }
     FwdCfg c = fwd_cfg(g, b, pl);
     DevGeom dg = dev_geom(g);
     dg.pix_major = (x_pm && x == xn && want_pix_major(g, b, PM_FWD)) ? 1 : 0;      // (one copy serves both inputs only when they are the same)
@@ -1856,6 +2040,20 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !wd || !dx) return fail("null tensor pointer");
     if (!dxn && x != xn) return fail("dxn is required when xn != x");
+    if (dw_direct(g, b)) {
+        DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
+        dim3 grid(ceil_div((long long)g->B * g->H * g->W, 256), ngroups(g));
+#define KAN_DWD(KIND) hipLaunchKernelGGL((k_dw_bwd_data<KIND>), grid, dim3(256), 0, (hipStream_t)stream, dz, x, xn, wd, dx, dxn, dgd, dbd, pl.Opad, pl.IPC, pl.KC, pl.Kpad)
+        switch (b->kind) {
+            case KAN_BASIS_BSPLINE: KAN_DWD(KAN_BASIS_BSPLINE); break;
+            case KAN_BASIS_RBF: KAN_DWD(KAN_BASIS_RBF); break;
+            case KAN_BASIS_POLY: KAN_DWD(KAN_BASIS_POLY); break;
+            case KAN_BASIS_FOURIER: KAN_DWD(KAN_BASIS_FOURIER); break;
+            default: KAN_DWD(KAN_BASIS_CHEBY); break;
+        }
+#undef KAN_DWD
+        return launch_ok("dw_bwd_data");
+    }
     BdCfg c = bd_cfg(g, pl);
     DevGeom dg = dev_geom(g);
     dg.pix_major = (dz_pm && want_pix_major(g, b, PM_BWD_DATA)) ? 1 : 0;
@@ -1903,6 +2101,20 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !dwp) return fail("null tensor pointer");
+    if (dw_direct(g, b)) {
+        DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
+        dim3 grid(pl.bwd_weight_splits, ngroups(g));
+#define KAN_DWW(KIND) hipLaunchKernelGGL((k_dw_bwd_weight<KIND>), grid, dim3(256), 0, (hipStream_t)stream, dz, x, xn, dwp, dgd, dbd, pl.K, pl.Opad, pl.bwd_weight_slab_elems)
+        switch (b->kind) {
+            case KAN_BASIS_BSPLINE: KAN_DWW(KAN_BASIS_BSPLINE); break;
+            case KAN_BASIS_RBF: KAN_DWW(KAN_BASIS_RBF); break;
+            case KAN_BASIS_POLY: KAN_DWW(KAN_BASIS_POLY); break;
+            case KAN_BASIS_FOURIER: KAN_DWW(KAN_BASIS_FOURIER); break;
+            default: KAN_DWW(KAN_BASIS_CHEBY); break;
+        }
+#undef KAN_DWW
+        return launch_ok("dw_bwd_weight");
+    }
     BwCfg c = bw_cfg(g, b, pl);
     DevGeom dg = dev_geom(g);
     dg.pix_major = (x_pm && dz_pm && x == xn && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;

@@ -100,7 +100,8 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
  *   wp (forward):   wp[k(item,p)][o],  item = tap*C + c (tap-major), T = kh*kw,
  *                   k = (item / IPC)*KC + (item % IPC)*P + p;  plane p = 0 is the base branch
  *                   (if any), planes hb.. are basis k = p - hb;  plan.packed_weight_bytes.
- *   wd (bwd-data):  optional (NULL to skip), plan.bwd_data_weight_bytes:
+ *   wd (bwd-data):  optional (NULL to skip), plan.bwd_data_weight_bytes (for depthwise groups -- C = 1, O <= 2, <= 9 taps,
+ *                   which run on direct kernels -- it is a plain copy of wp):
  *                   wd[tap*Opad32 + o][ct*128 + cl*P + p],  c = ct*(128/P) + cl.
  * Replaces nothing in the reference (layout only); sources are  base_conv[g].weight [O,C,kh,kw]  (kan_layers.py:159-166) and
  * spline_conv[g].weight / poly_conv[g].weight [O,C*n_basis,kh,kw], channel c*n_basis+k

@@ -157,15 +157,23 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // src_kind 0: base weights [O][C][T] -> plane 0;   src_kind 1: basis weights [O][C*nb][T] -> plane hb + q.
 // A 32x32 tile goes through LDS so that both the read (along the source's contiguous (channel,tap) axis) and the
 // write (along o) coalesce.
-struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad; };
+struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair; };
 
+// Row of (tap, channel c, plane p) in the forward layout.  pair == 0: tap-major items as described above.  pair == 1 (the
+// halo forward kernel, P = 9, C even): a step of KC = 18 rows is one tap of a channel PAIR, row 2p + (c & 1), steps
+// ordered (c / 2, tap) -- so that the two k-rows of an MFMA k-pair are the same plane of two channels, a fixed LDS
+// distance apart in the halo tile.
+__device__ __forceinline__ int wp_row(const PackGeo& q, int tap, int c, int p) {
+    if (q.pair) return ((c >> 1) * q.T + tap) * q.KC + 2 * p + (c & 1);
+    const int item = tap * q.C + c;                   // tap-major: all channels of a tap are contiguous in the depth axis
+    const int chunk = item / q.IPC;
+    return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
+}
 __device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
     int cq = j / q.T, tap = j - cq * q.T;
     int c = src_kind == 0 ? cq : cq / q.nb;
     int p = src_kind == 0 ? 0 : q.hb + (cq - c * q.nb);
-    int item = tap * q.C + c;                         // tap-major: all channels of a tap are contiguous in the depth axis
-    int chunk = item / q.IPC;
-    return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
+    return wp_row(q, tap, c, p);
 }
 
 __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, float* __restrict__ wp, PackGeo q, int src_kind,
@@ -267,8 +275,7 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
         if (col < ncol) {
             int hf = col >> 6, w = col & 63, cl = w / q.P, p = w - cl * q.P, c = hf * CH + cl;
             if (cl < CH && c < q.C && o < q.O) {
-                int item = tap * q.C + c, chunk = item / q.IPC;
-                v = wp[(size_t)(chunk * q.KC + (item - chunk * q.IPC) * q.P + p) * q.Opad + o];
+                v = wp[(size_t)wp_row(q, tap, c, p) * q.Opad + o];
             }
         }
         tile[ty + 8 * i][tx] = v;
@@ -612,6 +619,162 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
         int b, hw;
         if (g.pix_major) { hw = px / g.B; b = px - hw * g.B; }
         else { b = px / HoWo; hw = px - b * HoWo; }
+        float* zb = zs + (size_t)b * g.ybs + hw;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o_tile0 + w_o * 64 + mi * 32 + mfma_row(r, lane);
+                if (o < g.O) zb[(size_t)o * HoWo] = acc[mi][ni][r];
+            }
+        }
+    }
+}
+
+// ============================================================================ forward, halo variant
+// The tap-major kernel above expands every input value once per TAP it is used under (9x for a 3x3 kernel), and the
+// expansion is vector-ALU work that the fp32 MFMA has to share its issue slots with.  Here a workgroup expands the
+// inputs its 128-pixel tile can touch ONCE per channel pair into a zero-bordered halo tile in LDS,
+//     sH[channel of the pair][plane][cell],  cell = image-in-tile, row + 1, column + 1,
+// and the nine taps of that pair read it through shifted addresses: the B operand of (tap, c, p) for pixel n is
+// sH[c & 1][p][cell(n) + (r - 1) * (W + 2) + (t - 1)].  Weights come in the pair order of wp_row (one 18-row step = one tap
+// of one channel pair), so the two k-rows of an MFMA k-pair are the same plane of the two channels.  Staging per MFMA
+// drops by the tile's reuse factor (4.0 - 6.4x).  3x3, stride 1, pad 1, P = 9; tile = NIMG images x R rows x W columns.
+#define LDS_READ4H(r0, r1, r2, r3, addrA, addrB0, addrB1, oA0, oA1, oB)                                                 \
+    asm volatile("ds_read_b32 %0, %4 offset:%7\n\tds_read_b32 %1, %4 offset:%8\n\tds_read_b32 %2, %5 offset:%9\n\tds_read_b32 %3, %6 offset:%9" \
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addrA), "v"(addrB0), "v"(addrB1), "n"(oA0), "n"(oA1), "n"(oB) : "memory")
+
+template <int FAST, int WO, int W, int R, int NIMG>
+__global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo(
+    const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, DevBasis bs, int Opad,
+    int n_pairs, int pairs_per_split, long long slab_elems, unsigned x_bytes, int tiles_o) {
+    constexpr int TO = WO * 64, TP = 128, NT = WO * 2 * 64, NW = WO * 2, KC = 18, P = 9, T = 9;
+    constexpr int HW_ = W + 2, HIMG = (R + 2) * HW_, HALO = NIMG * HIMG;          // cells per plane
+    constexpr int RPI = 256 / TO, NQ = (KC + RPI - 1) / RPI;
+    static_assert(NIMG * R * W == TP && HALO % 2 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float sW[2 * KC * TO];
+    __shared__ float sH[2 * P * HALO];
+    __shared__ float sTab[KAN_MAX_TABLE];
+    __shared__ float sDump[NT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_o = wave >> 1, w_p = wave & 1;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, Mtot = g.B * HoWo;
+    const BlockId blk = xcd_block_order(true);
+    const int grp = blk.y / tiles_o;
+    const int px_tile0 = blk.x * TP, o_tile0 = (blk.y - grp * tiles_o) * TO;
+    x += (size_t)grp * g.C * HW;
+    z += (size_t)grp * g.O * HoWo;
+    wp += (size_t)grp * n_pairs * (T * KC) * Opad;
+
+    if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
+    for (int i = tid; i < 2 * P * HALO; i += NT) sH[i] = 0.f;              // borders (and out-of-image cells) stay zero for good
+
+    // the tile: NIMG images from b0, rows [h0, h0 + R)
+    const int b0 = px_tile0 / HoWo, h0 = (px_tile0 - b0 * HoWo) / W;
+    // cells this thread expands every channel pair (fixed): cell -> (channel of the pair, image, halo row, halo column)
+    constexpr int NCELL = 2 * HALO, CPT = (NCELL + NT - 1) / NT;
+    int c_src[CPT], c_dst[CPT]; unsigned c_ok = 0;                          // x element offset (without channel) / sH offset
+#pragma unroll
+    for (int k = 0; k < CPT; ++k) {
+        const int idx = tid + k * NT;
+        const int ch = idx / HALO, cell = idx - ch * HALO;
+        const int img = cell / HIMG, rc = cell - img * HIMG, hr = rc / HW_, hc = rc - hr * HW_;
+        const int b = b0 + img, h = h0 - 1 + hr, w = hc - 1;
+        const bool ok = idx < NCELL && b < g.B && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)W;
+        c_src[k] = b * (int)g.xbs + ch * HW + h * W + w;
+        c_dst[k] = ch * (P * HALO) + cell;
+        c_ok |= (ok ? 1u : 0u) << k;
+    }
+    const kan_rsrc x_rs = make_rsrc(x, x_bytes);
+
+    // B-operand addresses of this lane's two pixels (kh2 selects the channel of the pair)
+    const int kh2 = lane >> 5;
+    unsigned vb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = w_p * 64 + q * 32 + (lane & 31);
+        const int img = n / (R * W), rem = n - img * (R * W), row = rem / W, col = rem - row * W;
+        vb[q] = lds_addr(sH + kh2 * (P * HALO) + img * HIMG + (row + 1) * HW_ + (col + 1));
+    }
+    const int ao = w_o * 64 + (lane & 31);
+    const unsigned wlane = (unsigned)((lane / (TO / 4)) * Opad + (lane % (TO / 4)) * 4) * 4u;
+    const int wv = wave;
+
+    auto issue_w = [&](int step, int buf) {                 // async copy of weight step `step` (18 rows x TO) into sW[buf]
+        const char* wsrc = (const char*)(wp + (size_t)step * KC * Opad + o_tile0);
+        float* dW = sW + buf * (KC * TO);
+#pragma unroll
+        for (int j = 0; j < (NQ + NW - 1) / NW; ++j) {
+            const int q = j * NW + wv;
+            if (q < NQ) {
+                if (KC % RPI == 0 || q * RPI + (int)(lane / (TO / 4)) < KC)
+                    glds16((const float*)(wsrc + (size_t)q * RPI * Opad * 4 + wlane), dW + q * 256);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int cp0 = blk.z * pairs_per_split, cp1 = min(n_pairs, cp0 + pairs_per_split);
+    int buf = 0;
+    if (cp0 < cp1) issue_w(cp0 * T, 0);
+    __syncthreads();                                         // sTab + zero fill visible
+    for (int cp = cp0; cp < cp1; ++cp) {
+        // ---- expand this channel pair's halo (everyone is past the previous pair's last MFMA step: barrier at its tap 8 ... see below)
+        float xv[CPT];
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            xv[k] = buf_load(x_rs, ((c_ok >> k) & 1u) ? (unsigned)(c_src[k] + 2 * cp * HW) * 4u : KAN_OOB);
+        __syncthreads();                                     // all waves have finished reading the previous pair's halo
+#pragma unroll
+        for (int k = 0; k < CPT; ++k)
+            if ((c_ok >> k) & 1u) stage_unit<KAN_BASIS_BSPLINE, FAST>(bs, sTab, true, xv[k], xv[k], sH + c_dst[k], HALO, sDump + tid);
+        // ---- nine taps: one weight step each
+#pragma unroll 1
+        for (int tap = 0; tap < T; ++tap) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                 // weights of this step landed everywhere; (tap 0) halo visible
+            const int nxt = cp * T + tap + 1;
+            if (nxt < cp1 * T) issue_w(nxt, buf ^ 1);
+            const int r = tap / 3, t = tap - r * 3;
+            const unsigned sh = (unsigned)(((r - 1) * HW_ + (t - 1)) * 4);
+            const unsigned aw = lds_addr(sW + buf * (KC * TO) + kh2 * TO + ao), ab0 = vb[0] + sh, ab1 = vb[1] + sh;
+            float fa[2][2], fb[2][2];
+            LDS_READ4H(fa[0][0], fa[0][1], fb[0][0], fb[0][1], aw, ab0, ab1, 0, 32 * 4, 0);
+#pragma unroll
+            for (int kk = 0; kk < P; ++kk) {
+                const int c_ = kk & 1, n_ = c_ ^ 1;
+                if (kk + 1 < P) {
+                    LDS_READ4H(fa[n_][0], fa[n_][1], fb[n_][0], fb[n_][1], aw, ab0, ab1, (2 * (kk + 1)) * TO * 4, (2 * (kk + 1)) * TO * 4 + 128,
+                               (kk + 1) * HALO * 4);
+                    LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 4);
+                } else {
+                    LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 0);
+                }
+                acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);
+                acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);
+                acc[1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[1][0]);
+                acc[1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[1][1]);
+            }
+            buf ^= 1;
+        }
+    }
+
+    // ---- store (as k_conv_fwd)
+    float* zs = z + (size_t)blk.z * slab_elems;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int px = px_tile0 + w_p * 64 + ni * 32 + (lane & 31);
+        if (px >= Mtot) continue;
+        const int b = px / HoWo, hw = px - b * HoWo;
         float* zb = zs + (size_t)b * g.ybs + hw;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
@@ -1651,6 +1814,18 @@ bool big_tiles(const KanBasis* b, const KanPlan& pl) {
     const int f = fast_variant(b);
     return !off && pl.Opad % 256 == 0 && (f == 1 || f == 2 || f == 4 || f == 6);
 }
+// Halo forward kernel (k_conv_fwd_halo): 3x3 / stride 1 / pad 1 layers of the default B-spline specs whose 128-pixel
+// tiles are whole row blocks of one image or whole images (the KAN-VGG shapes 32x32, 16x16, 8x8, 4x4).
+bool halo_fwd(const KanGeom* g, const KanBasis* b) {
+    static const int off = getenv("KAN_HALO") ? (atoi(getenv("KAN_HALO")) == 0) : 0;       // KAN_HALO=0: A/B switch (tuning only)
+    const int f = fast_variant(b);
+    if (off || !(f == 1 || f == 2)) return false;
+    if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
+    if ((g->C & 1) || g->O % 128 != 0) return false;
+    if (want_pix_major(g, b, PM_FWD)) return false;
+    const int W = g->W, H = g->H;
+    return (W == 32 && H % 4 == 0) || (W == 16 && H % 8 == 0) || (W == 8 && H == 8) || (W == 4 && H == 4);
+}
 struct FwdCfg { int TO, TP, tiles_o, tiles_p, chunks, splits, slots; };
 FwdCfg fwd_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     FwdCfg c;
@@ -1661,6 +1836,10 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     c.tiles_p = ceil_div((long long)g->B * g->Ho * g->Wo, c.TP);
     c.chunks = pl.Kpad / pl.KC;
     c.splits = pick_splits((long long)c.tiles_o * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * ngroups(g), c.slots);
+    if (halo_fwd(g, b)) {                            // the halo kernel splits the depth axis between channel pairs (9 steps each)
+        const int n_pairs = g->C / 2, pps = ceil_div(n_pairs, c.splits < n_pairs ? c.splits : n_pairs);
+        c.splits = ceil_div(n_pairs, pps);
+    }
     return c;
 }
 // With dead-tap skipping the tiles of one launch carry 4/9 ... 9/9 of the nominal work depending on their pixel
@@ -1851,6 +2030,7 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
     PackGeo q;
     q.O = g->O; q.C = g->C; q.T = g->kh * g->kw; q.P = pl.P; q.hb = b->act != KAN_ACT_NONE; q.nb = b->n_basis;
     q.IPC = flat ? 1 : pl.IPC; q.KC = flat ? pl.P : pl.KC; q.Opad = pl.Opad;
+    q.pair = (!flat && halo_fwd(g, b)) ? 1 : 0;
     return q;
 }
 
@@ -1980,6 +2160,30 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         return launch_ok("dw_fwd");
     }
     FwdCfg c = fwd_cfg(g, b, pl);
+    if (halo_fwd(g, b)) {
+        if (x != xn) return fail("internal: halo forward kernel needs a single input tensor");
+        DevGeom dgh = dev_geom(g); DevBasis dbh = dev_basis(b);
+        const int n_pairs = g->C / 2, pps = ceil_div(n_pairs, pl.fwd_splits), fv = fast_variant(b);
+        if ((long long)c.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
+        dim3 gridh(c.tiles_p, c.tiles_o * ngroups(g), pl.fwd_splits);
+#define KAN_HALO(F, WOV, WV, RV, NV) \
+    hipLaunchKernelGGL((k_conv_fwd_halo<F, WOV, WV, RV, NV>), gridh, dim3(WOV * 128), 0, (hipStream_t)stream, x, wp, z, dgh, dbh, pl.Opad, n_pairs, pps, pl.fwd_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), c.tiles_o)
+#define KAN_HALO_SHAPE(F, WOV)                                              \
+    do {                                                                    \
+        if (g->W == 32) KAN_HALO(F, WOV, 32, 4, 1);                          \
+        else if (g->W == 16) KAN_HALO(F, WOV, 16, 8, 1);                     \
+        else if (g->W == 8) KAN_HALO(F, WOV, 8, 8, 2);                       \
+        else KAN_HALO(F, WOV, 4, 4, 8);                                      \
+    } while (0)
+        if (c.TO == 256 && fv == 1) KAN_HALO_SHAPE(1, 4);
+        else if (c.TO == 256) KAN_HALO_SHAPE(2, 4);
+        else if (c.TO == 128 && fv == 1) KAN_HALO_SHAPE(1, 2);
+        else if (c.TO == 128) KAN_HALO_SHAPE(2, 2);
+        else return fail("internal: halo forward kernel needs O % 128 == 0");
+#undef KAN_HALO_SHAPE
+#undef KAN_HALO
+        return launch_ok("conv_fwd_halo");
+    }
     DevGeom dg = dev_geom(g);
     dg.pix_major = (x_pm && x == xn && want_pix_major(g, b, PM_FWD)) ? 1 : 0;      // (one copy serves both inputs only when they are the same)
     if (dg.pix_major) { x = x_pm; xn = x_pm; }

@@ -725,14 +725,16 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
 
     const int cp0 = blk.z * pairs_per_split, cp1 = min(n_pairs, cp0 + pairs_per_split);
     int buf = 0;
-    if (cp0 < cp1) issue_w(cp0 * T, 0);
-    __syncthreads();                                         // sTab + zero fill visible
-    for (int cp = cp0; cp < cp1; ++cp) {
-        // ---- expand this channel pair's halo (everyone is past the previous pair's last MFMA step: barrier at its tap 8 ... see below)
-        float xv[CPT];
+    float xv[CPT];                                           // the pair's input values, requested half a pair ahead
+    auto load_pair = [&](int cp) {
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
             xv[k] = buf_load(x_rs, ((c_ok >> k) & 1u) ? (unsigned)(c_src[k] + 2 * cp * HW) * 4u : KAN_OOB);
+    };
+    if (cp0 < cp1) { issue_w(cp0 * T, 0); load_pair(cp0); }
+    __syncthreads();                                         // sTab + zero fill visible
+    for (int cp = cp0; cp < cp1; ++cp) {
+        // ---- expand this channel pair's halo
         __syncthreads();                                     // all waves have finished reading the previous pair's halo
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
@@ -744,6 +746,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
             __syncthreads();                                 // weights of this step landed everywhere; (tap 0) halo visible
             const int nxt = cp * T + tap + 1;
             if (nxt < cp1 * T) issue_w(nxt, buf ^ 1);
+            if (tap == 4 && cp + 1 < cp1) load_pair(cp + 1);
             const int r = tap / 3, t = tap - r * 3;
             const unsigned sh = (unsigned)(((r - 1) * HW_ + (t - 1)) * 4);
             const unsigned aw = lds_addr(sW + buf * (KC * TO) + kh2 * TO + ao), ab0 = vb[0] + sh, ab1 = vb[1] + sh;

@@ -648,7 +648,8 @@ template <int FAST, int WO, int W, int R, int NIMG>
 __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo(
     const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, DevBasis bs, int Opad,
     int n_pairs, int pairs_per_split, long long slab_elems, unsigned x_bytes, int tiles_o) {
-    constexpr int TO = WO * 64, TP = 128, NT = WO * 2 * 64, NW = WO * 2, KC = 18, P = 9, T = 9;
+    constexpr int TO = WO * 64, TP = 128, NT = WO * 2 * 64, NW = WO * 2, P = fast_planes(FAST), KC = 2 * P, T = 9;
+    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : KAN_BASIS_BSPLINE;
     constexpr int HW_ = W + 2, HIMG = (R + 2) * HW_, HALO = NIMG * HIMG;          // cells per plane
     constexpr int RPI = 256 / TO, NQ = (KC + RPI - 1) / RPI;
     static_assert(NIMG * R * W == TP && HALO % 2 == 0, "tile shape");
@@ -738,7 +739,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
         __syncthreads();                                     // all waves have finished reading the previous pair's halo
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
-            if ((c_ok >> k) & 1u) stage_unit<KAN_BASIS_BSPLINE, FAST>(bs, sTab, true, xv[k], xv[k], sH + c_dst[k], HALO, sDump + tid);
+            if ((c_ok >> k) & 1u) stage_unit<KIND, FAST>(bs, sTab, true, xv[k], xv[k], sH + c_dst[k], HALO, sDump + tid);
         // ---- nine taps: one weight step each
 #pragma unroll 1
         for (int tap = 0; tap < T; ++tap) {
@@ -1822,7 +1823,7 @@ bool big_tiles(const KanBasis* b, const KanPlan& pl) {
 bool halo_fwd(const KanGeom* g, const KanBasis* b) {
     static const int off = getenv("KAN_HALO") ? (atoi(getenv("KAN_HALO")) == 0) : 0;       // KAN_HALO=0: A/B switch (tuning only)
     const int f = fast_variant(b);
-    if (off || !(f == 1 || f == 2)) return false;
+    if (off || !(f == 1 || f == 2 || f == 5 || f == 6)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
     if ((g->C & 1) || g->O % 128 != 0) return false;
     if (want_pix_major(g, b, PM_FWD)) return false;
@@ -1976,6 +1977,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         const bool use18 = (long long)i18 * pl->P * 16 > (long long)i16 * pl->P * 18;   // i18*P/18 > i16*P/16
         pl->KC = use18 ? 18 : 16;
         pl->IPC = use18 ? i18 : i16;
+        if (halo_fwd(g, b)) { pl->KC = 2 * pl->P; pl->IPC = 2; }      // pair order: one step = one tap of a channel pair, no pad rows
     }
     pl->Kpad = ceil_div(g->C * T, pl->IPC) * pl->KC;
     pl->Opad = round_up(g->O, 64);
@@ -2179,10 +2181,13 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         else KAN_HALO(F, WOV, 4, 4, 8);                                      \
     } while (0)
         if (c.TO == 256 && fv == 1) KAN_HALO_SHAPE(1, 4);
-        else if (c.TO == 256) KAN_HALO_SHAPE(2, 4);
+        else if (c.TO == 256 && fv == 2) KAN_HALO_SHAPE(2, 4);
+        else if (c.TO == 256 && fv == 6) KAN_HALO_SHAPE(6, 4);
         else if (c.TO == 128 && fv == 1) KAN_HALO_SHAPE(1, 2);
-        else if (c.TO == 128) KAN_HALO_SHAPE(2, 2);
-        else return fail("internal: halo forward kernel needs O % 128 == 0");
+        else if (c.TO == 128 && fv == 2) KAN_HALO_SHAPE(2, 2);
+        else if (c.TO == 128 && fv == 5) KAN_HALO_SHAPE(5, 2);
+        else if (c.TO == 128 && fv == 6) KAN_HALO_SHAPE(6, 2);
+        else return fail("internal: no halo forward kernel for this basis / tile");
 #undef KAN_HALO_SHAPE
 #undef KAN_HALO
         return launch_ok("conv_fwd_halo");

@@ -129,6 +129,30 @@ def test_many_planes_single_item_steps(gs, C, O, H, B, gpu_lib):
     _compare(layer, _cfg("bspline", C, O, act="silu", grid_size=gs), torch.randn(B, C, H, H), tol_scale=2.0)
 
 
+HALO = [
+    # (factory key, C, O, H, B): 3x3 / stride 1 / pad 1 layers on the plane sizes the halo forward kernel serves, one per
+    # compile-time spec and tile width (B-spline SiLU / GELU, ChebyKAN degree 3, recurrence degree 3; 128- and 256-output tiles)
+    ("KAN", 64, 128, 16, 8, dict(base_activation=nn.SiLU)), ("KAN", 32, 256, 8, 6, dict(base_activation=nn.GELU)),
+    ("KAN", 16, 256, 4, 40, dict(base_activation=nn.SiLU)), ("KAN", 6, 128, 32, 3, dict(base_activation=nn.SiLU)),
+    ("ChebyKAN", 32, 128, 8, 8, dict(degree=3)), ("LucasKAN", 64, 128, 16, 4, dict(base_activation=nn.SiLU)),
+    ("JacobiKAN", 32, 256, 8, 8, dict(base_activation=nn.SiLU)), ("LaguerreKAN", 20, 128, 4, 24, {}),
+]
+
+
+@pytest.mark.parametrize("case", HALO, ids=lambda c: f"{c[0]}-C{c[1]}-O{c[2]}-{c[3]}x{c[3]}")
+def test_halo_forward_shapes_vs_oracle(case, gpu_lib):
+    name, C, O, H, B, kw = case
+    torch.manual_seed(C + O + H)
+    layer = K.CONV_KAN_FACTORY[name](C, O, 3, **kw)
+    act = {nn.SiLU: "silu", nn.GELU: "gelu"}.get(kw.get("base_activation", nn.GELU), "gelu")
+    kind = {"KAN": "bspline", "ChebyKAN": "cheby", "LucasKAN": "lucas", "JacobiKAN": "jacobi", "LaguerreKAN": "laguerre"}[name]
+    extra = {"JacobiKAN": {"a": 1.0, "b": 1.0}, "LaguerreKAN": {"alpha": 1.0}}.get(name, {})
+    cfg = _cfg(kind, C, O, act=act, degree=3, extra=extra)
+    if kind == "laguerre":
+        cfg["act"] = "gelu"
+    _compare(layer, cfg, torch.randn(B, C, H, H), tol_scale=2.0)
+
+
 def test_nan_and_out_of_grid_inputs(gpu_lib):
     """x outside the knot span has all bases zero (kan_layers.py:209); NaN inputs propagate through the base branch only."""
     torch.manual_seed(1)

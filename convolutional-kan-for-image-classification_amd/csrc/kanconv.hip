@@ -2069,7 +2069,7 @@ int group_lanes(int HW) {          // (more elements per lane was measured: no g
 // ============================================================================ C ABI
 extern "C" {
 
-const char* kan_version(void) { return "kanconv 0.4 (gfx950, fp32 MFMA 32x32x2, 128- and 256-output tiles)"; }
+const char* kan_version(void) { return "kanconv 0.5 (gfx950, fp32 MFMA 32x32x2, halo forward, 128/256-output tiles)"; }
 const char* kan_last_error(void) { return g_err; }
 
 int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {

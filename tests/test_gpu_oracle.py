@@ -136,6 +136,9 @@ HALO = [
     ("KAN", 16, 256, 4, 40, dict(base_activation=nn.SiLU)), ("KAN", 6, 128, 32, 3, dict(base_activation=nn.SiLU)),
     ("ChebyKAN", 32, 128, 8, 8, dict(degree=3)), ("LucasKAN", 64, 128, 16, 4, dict(base_activation=nn.SiLU)),
     ("JacobiKAN", 32, 256, 8, 8, dict(base_activation=nn.SiLU)), ("LaguerreKAN", 20, 128, 4, 24, {}),
+    # ragged last tile: images missing from the last 128-pixel tile (8x8: 2 images per tile, 4x4: 8 per tile), one image only
+    ("KAN", 8, 128, 8, 5, dict(base_activation=nn.SiLU)), ("KAN", 8, 128, 4, 13, dict(base_activation=nn.SiLU)),
+    ("KAN", 4, 128, 16, 1, dict(base_activation=nn.SiLU)), ("KAN", 2, 128, 32, 1, dict(base_activation=nn.GELU)),
 ]
 
 

@@ -817,6 +817,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const int px_tile0 = (perm.n ? (int)perm.idx[blk.x] : blk.x) * TP, ct = blk.y - grp * n_ct;
     const int ncol = n_ct * 128;
     const int pxl = (wave & 1) * 64 + lane, ol0 = wave >> 1;
+    const bool idle_rows = (ct * 2 + w_r) * CH >= g.C;        // this wave's 64-row half lies wholly in the channel padding (last tile)
     {
         const size_t xo = (size_t)grp * g.C * HW;
         x += xo; xn += xo; dx += xo; if (dxn) dxn += xo;
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         const float* cW = smem + cur * (2 * KD * 128);
         const float* cG = cW + KD * 128;
         const unsigned aw = lds_addr(cW + kh2 * 128 + ar), ag = lds_addr(cG + kh2 * TP + bp);
-        KAN_MFMA_STEP(KD / 2, aw, 128, ag, TP);
+        if (!idle_rows) KAN_MFMA_STEP(KD / 2, aw, 128, ag, TP);     // (waves whose 64 rows hold no channel leave the matrix pipe to others)
     }
 
     // ---- epilogue: per 64-row half, G -> LDS, contract the P planes of each channel with plane'(x)

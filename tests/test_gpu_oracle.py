@@ -139,6 +139,8 @@ HALO = [
     # ragged last tile: images missing from the last 128-pixel tile (8x8: 2 images per tile, 4x4: 8 per tile), one image only
     ("KAN", 8, 128, 8, 5, dict(base_activation=nn.SiLU)), ("KAN", 8, 128, 4, 13, dict(base_activation=nn.SiLU)),
     ("KAN", 4, 128, 16, 1, dict(base_activation=nn.SiLU)), ("KAN", 2, 128, 32, 1, dict(base_activation=nn.GELU)),
+    # groups folded into the halo launch (per-group x / weight / z offsets)
+    ("KAN", 32, 256, 8, 4, dict(base_activation=nn.SiLU, groups=2)), ("LucasKAN", 24, 384, 4, 16, dict(base_activation=nn.SiLU, groups=3)),
 ]
 
 
@@ -150,7 +152,7 @@ def test_halo_forward_shapes_vs_oracle(case, gpu_lib):
     act = {nn.SiLU: "silu", nn.GELU: "gelu"}.get(kw.get("base_activation", nn.GELU), "gelu")
     kind = {"KAN": "bspline", "ChebyKAN": "cheby", "LucasKAN": "lucas", "JacobiKAN": "jacobi", "LaguerreKAN": "laguerre"}[name]
     extra = {"JacobiKAN": {"a": 1.0, "b": 1.0}, "LaguerreKAN": {"alpha": 1.0}}.get(name, {})
-    cfg = _cfg(kind, C, O, act=act, degree=3, extra=extra)
+    cfg = _cfg(kind, C, O, act=act, degree=3, extra=extra, groups=kw.get("groups", 1))
     if kind == "laguerre":
         cfg["act"] = "gelu"
     _compare(layer, cfg, torch.randn(B, C, H, H), tol_scale=2.0)

@@ -1420,9 +1420,9 @@ __global__ __launch_bounds__(256) void k_dw_fwd(const float* __restrict__ x, con
     __shared__ float sWt[DW_MAX_TP * 2];             // [tap*P + p][o]
     const int grp = blockIdx.y, T = g.kh * g.kw, P = bs.P, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
     if (threadIdx.x < KAN_MAX_TABLE) sTab[threadIdx.x] = bs.tab[threadIdx.x];
-    for (int i = threadIdx.x; i < T * P * g.O; i += 256) {
-        const int o = i % g.O, tp = i / g.O, tap = tp / P, p = tp - tap * P;
-        sWt[tp * 2 + o] = wp[((size_t)grp * Kpad + dw_krow(tap, p, IPC, KC, P)) * Opad + o];
+    for (int i = threadIdx.x; i < T * P * 2; i += 256) {          // (second output slot is zero when the group has one output)
+        const int o = i & 1, tp = i >> 1, tap = tp / P, p = tp - tap * P;
+        sWt[i] = o < g.O ? wp[((size_t)grp * Kpad + dw_krow(tap, p, IPC, KC, P)) * Opad + o] : 0.f;
     }
     __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -1454,9 +1454,9 @@ __global__ __launch_bounds__(256) void k_dw_bwd_data(const float* __restrict__ d
     __shared__ float sWt[DW_MAX_TP * 2];
     const int grp = blockIdx.y, T = g.kh * g.kw, P = bs.P, HoWo = g.Ho * g.Wo, HW = g.H * g.W;
     if (threadIdx.x < KAN_MAX_TABLE) sTab[threadIdx.x] = bs.tab[threadIdx.x];
-    for (int i = threadIdx.x; i < T * P * g.O; i += 256) {
-        const int o = i % g.O, tp = i / g.O, tap = tp / P, p = tp - tap * P;
-        sWt[tp * 2 + o] = wp[((size_t)grp * Kpad + dw_krow(tap, p, IPC, KC, P)) * Opad + o];
+    for (int i = threadIdx.x; i < T * P * 2; i += 256) {          // (second output slot is zero when the group has one output)
+        const int o = i & 1, tp = i >> 1, tap = tp / P, p = tp - tap * P;
+        sWt[i] = o < g.O ? wp[((size_t)grp * Kpad + dw_krow(tap, p, IPC, KC, P)) * Opad + o] : 0.f;
     }
     __syncthreads();
     const int e = blockIdx.x * 256 + threadIdx.x;

@@ -1825,6 +1825,7 @@ bool halo_fwd(const KanGeom* g, const KanBasis* b) {
     static const int off = getenv("KAN_HALO") ? (atoi(getenv("KAN_HALO")) == 0) : 0;       // KAN_HALO=0: A/B switch (tuning only)
     const int f = fast_variant(b);
     if (off || !(f == 1 || f == 2 || f == 5 || f == 6)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3
+    if (b->kind == KAN_BASIS_POLY && b->order == 0) return false;          // order 0 = basis on a second, pre-normalised tensor (LegendreKAN): tap-major kernel
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
     if ((g->C & 1) || g->O % 128 != 0) return false;
     if (want_pix_major(g, b, PM_FWD)) return false;

@@ -100,9 +100,11 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
  *   wp (forward):   wp[k(item,p)][o],  item = tap*C + c (tap-major), T = kh*kw,
  *                   k = (item / IPC)*KC + (item % IPC)*P + p;  plane p = 0 is the base branch
  *                   (if any), planes hb.. are basis k = p - hb;  plan.packed_weight_bytes.
- *                   (3x3 / stride 1 / pad 1 layers of the default B-spline specs on 32x32, 16x16, 8x8, 4x4 planes use the
- *                   pair order of the halo forward kernel instead: k = ((c/2)*T + tap)*18 + 2p + (c&1).  wp is opaque to
- *                   the caller either way: it is only ever passed back to kan_conv_fwd of the same geometry.)
+ *                   (3x3 / stride 1 / pad 1 layers of the default B-spline, ChebyKAN degree-3 and one-input recurrence
+ *                   degree-3 specs on 32x32, 16x16, 8x8, 4x4 planes use the pair order of the halo forward kernel instead:
+ *                   k = ((c/2)*T + tap)*2P + 2p + (c&1).  Poly specs with order = 0 -- basis on a second tensor xn != x,
+ *                   LegendreKAN -- never do.  wp is opaque to the caller either way: it is only ever passed back to
+ *                   kan_conv_fwd of the same geometry and basis.)
  *   wd (bwd-data):  optional (NULL to skip), plan.bwd_data_weight_bytes (for depthwise groups -- C = 1, O <= 2, <= 9 taps,
  *                   which run on direct kernels -- it is a plain copy of wp):
  *                   wd[tap*Opad32 + o][ct*128 + cl*P + p],  c = ct*(128/P) + cl.

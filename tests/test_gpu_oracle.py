@@ -141,6 +141,9 @@ HALO = [
     ("KAN", 4, 128, 16, 1, dict(base_activation=nn.SiLU)), ("KAN", 2, 128, 32, 1, dict(base_activation=nn.GELU)),
     # groups folded into the halo launch (per-group x / weight / z offsets)
     ("KAN", 32, 256, 8, 4, dict(base_activation=nn.SiLU, groups=2)), ("LucasKAN", 24, 384, 4, 16, dict(base_activation=nn.SiLU, groups=3)),
+    # halo-shaped but NOT halo-served: LegendreKAN evaluates its basis on a second (batch-normalised) tensor, which the
+    # one-input halo kernel cannot take -- the plan must keep it on the tap-major kernel and its weight order
+    ("LegendreKAN", 16, 128, 8, 4, {}), ("LegendreKAN", 4, 256, 16, 2, {}),
 ]
 
 
@@ -150,10 +153,11 @@ def test_halo_forward_shapes_vs_oracle(case, gpu_lib):
     torch.manual_seed(C + O + H)
     layer = K.CONV_KAN_FACTORY[name](C, O, 3, **kw)
     act = {nn.SiLU: "silu", nn.GELU: "gelu"}.get(kw.get("base_activation", nn.GELU), "gelu")
-    kind = {"KAN": "bspline", "ChebyKAN": "cheby", "LucasKAN": "lucas", "JacobiKAN": "jacobi", "LaguerreKAN": "laguerre"}[name]
+    kind = {"KAN": "bspline", "ChebyKAN": "cheby", "LucasKAN": "lucas", "JacobiKAN": "jacobi", "LaguerreKAN": "laguerre",
+            "LegendreKAN": "legendre"}[name]
     extra = {"JacobiKAN": {"a": 1.0, "b": 1.0}, "LaguerreKAN": {"alpha": 1.0}}.get(name, {})
     cfg = _cfg(kind, C, O, act=act, degree=3, extra=extra, groups=kw.get("groups", 1))
-    if kind == "laguerre":
+    if kind in ("laguerre", "legendre"):
         cfg["act"] = "gelu"
     _compare(layer, cfg, torch.randn(B, C, H, H), tol_scale=2.0)
 

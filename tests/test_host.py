@@ -57,6 +57,16 @@ def test_plan_arithmetic():
     assert (g.Ho, g.Wo) == (55, 55) and p.P == 5 and p.KC == 16 and p.IPC == 3
 
 
+def test_plan_keeps_two_input_layers_off_the_pair_order():
+    """Halo-shaped 3x3 layers pack their forward weights in channel-pair order (IPC 2, KC 2P) for the one-input halo kernel;
+    LegendreKAN (order 0: basis on a second, pre-normalised tensor) must stay on the tap-major order and kernel."""
+    leg = (1.0, 1.0, 0.0, 1.5, 0.0, -0.5, 5 / 3, 0.0, -2 / 3)
+    _, _, one = _plan(16, 128, 8, kind=L.BASIS_POLY, nb=4, order=1, act=L.ACT_GELU, table=leg)
+    _, _, two = _plan(16, 128, 8, kind=L.BASIS_POLY, nb=4, order=0, act=L.ACT_IDENTITY, table=leg)
+    assert (one.P, one.IPC, one.KC) == (5, 2, 10)
+    assert two.P == 5 and (two.IPC, two.KC) != (2, 10)
+
+
 def test_plan_with_groups_scales_per_group_blocks():
     table = tuple(float(v) for v in torch.linspace(-2.2, 2.2, 12).tolist())
     mk = lambda G: ops.ConvSpec(kind=L.BASIS_BSPLINE, n_basis=8, order=3, act=L.ACT_SILU, p0=0.0, p1=0.0, table=table, kernel=(3, 3),

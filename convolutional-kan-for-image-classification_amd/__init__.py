@@ -14,3 +14,5 @@ __version__ = "0.1.0"
 from .layers.poly_layers import (LegendreKANConv2DLayer, BersnsteinKANConv2DLayer, FourierKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,   # noqa: F401,E402
                                  JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 from .layers.conv_layers import KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv1DLayer   # noqa: F401,E402
+from .layers.relu_layers import ReLUConvNDLayer, ReLUKANConv2DLayer, ReLUKANConv1DLayer   # noqa: F401,E402
+from .layers.kan_conv import relukan_conv   # noqa: F401,E402

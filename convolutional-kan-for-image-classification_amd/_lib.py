@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libkanconv.so")
 
 KAN_MAX_PLANES = 16
 KAN_MAX_TABLE = 32
-BASIS_BSPLINE, BASIS_RBF, BASIS_CHEBY, BASIS_POLY, BASIS_FOURIER = 0, 1, 2, 3, 4
+BASIS_BSPLINE, BASIS_RBF, BASIS_CHEBY, BASIS_POLY, BASIS_FOURIER, BASIS_RELU = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_IDENTITY, ACT_GELU, ACT_SILU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_TANH = -1, 0, 1, 2, 3, 4, 5, 6
 
 
@@ -25,7 +25,7 @@ class KanGeom(C.Structure):
 
 class KanBasis(C.Structure):
     _fields_ = [("kind", C.c_int), ("n_basis", C.c_int), ("order", C.c_int), ("act", C.c_int),
-                ("p0", C.c_float), ("p1", C.c_float), ("table", C.c_float * KAN_MAX_TABLE)]
+                ("p0", C.c_float), ("p1", C.c_float), ("table", C.c_float * KAN_MAX_TABLE), ("chan_table", C.c_void_p)]
 
 
 class KanPlan(C.Structure):

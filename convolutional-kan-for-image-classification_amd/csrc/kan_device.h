@@ -16,6 +16,7 @@ struct DevBasis {            // by-value kernel argument
     float p0, p1, inv_h;
     float g0, gN;            // B-spline: first / last knot (the span outside which every basis is zero)
     float tab[KAN_MAX_TABLE];
+    const float* ctab;       // ReLU-KAN: per-channel phases [C][2][nb] in device memory
 };
 
 // ---------------------------------------------------------------- activations
@@ -128,9 +129,10 @@ __device__ __forceinline__ bool bspline_uniform(int S, float x, const float* kn,
 // xa feeds the base branch, xb feeds the basis (xa == xb except for FastKAN).
 // KIND is a template parameter so that each kernel instantiation carries ONE basis family's code
 // (all families inlined at every staging site made the kernels thrash the instruction cache).
+// `c` is the channel inside its group; only families with per-channel parameters (ReLU-KAN) look at it.
 template <int KIND, bool DERIV>
 __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs, float xa, float xb,
-                                           float (&v)[KAN_PMAX]) {
+                                           float (&v)[KAN_PMAX], int c = 0) {
 #pragma unroll
     for (int p = 0; p < KAN_PMAX; ++p) v[p] = 0.f;
     const int hb = bs.hb;
@@ -173,6 +175,26 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
                 float sn, cs;
                 sincosf(k * xb, &sn, &cs);
                 v[p] = is_cos ? (DERIV ? -k * sn : cs) : (DERIV ? k * cs : sn);
+            }
+        }
+    } else if (KIND == KAN_BASIS_RELU) {
+        // relu_kan_layers.py:127-131: x1 = relu(x - lo), x2 = relu(hi - x), q = x1 * x2 * r, plane = q * q, in that order.
+        // q' terms: dq/dx = r (x2 - x1) wherever q != 0 (and 2q kills the rest), dq/dlo = -r x2, dq/dhi = r x1.
+        // Non-derivative modes (bs.order): 0 value, 1 d/dlo, 2 d/dhi (base plane zero) -- the weight-gradient kernel run
+        // on mode 1 / 2 gives the phase gradients their data-dependent factor.
+        const float* lo = bs.ctab + (size_t)c * 2 * bs.nb;
+        const float* hi = lo + bs.nb;
+        const float r = bs.p0;
+        const int mode = DERIV ? 3 : bs.order;
+        if (hb && mode != 0 && !DERIV) v[0] = 0.f;
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p) {
+            const int j = p - hb;
+            if (j >= 0 && j < bs.nb) {
+                const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(hi[j] - xb, 0.f);
+                const float q = x1 * x2 * r;
+                const float q2 = 2.0f * q * r;
+                v[p] = mode == 0 ? q * q : mode == 1 ? -(q2 * x2) : mode == 2 ? q2 * x1 : q2 * (x2 - x1);
             }
         }
     } else if (KIND == KAN_BASIS_POLY) {

@@ -325,7 +325,7 @@ __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgc
 
 template <int KIND, int FAST>
 __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab, bool inb, float xa, float xb,
-                                           float* col, int ld, float* dump) {
+                                           float* col, int ld, float* dump, int c = 0) {
     if (KIND == KAN_BASIS_RBF && (FAST == 3 || FAST == 8)) {          // 8 (FastKAN default) or 5 (grid_size 5, as kan_vgg.py builds it) centres
         // utils/utils.py:33 with hardware exp2: exp(-u^2) = exp2(-u^2 log2 e), u = (x - c_g) / d
         col[0] = inb ? silu_fast(xa) : 0.f;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
         }
     } else {
         float v[KAN_PMAX];
-        kan_planes<KIND, false>(bs, sTab, xa, xb, v);
+        kan_planes<KIND, false>(bs, sTab, xa, xb, v, inb ? c : 0);
 #pragma unroll
         for (int p = 0; p < KAN_PMAX; ++p)
             if (p < P) col[p * ld] = inb ? v[p] : 0.f;
@@ -509,11 +509,12 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
     const unsigned wlane = (unsigned)((lane / (TO / 4)) * Opad + (lane % (TO / 4)) * 4) * 4u;   // this lane inside a 1-KiB weight block
 
     float xa[UMAX], xb[UMAX]; unsigned inb_mask = 0;
+    int s_ch = 0;                                            // the step whose gathers sit in xa / xb (per-channel bases decode c from it)
 
     // issue(ch, buf): gather the x values of step ch into registers; start the async copy of its weight rows
     // (KC rows x TO floats, a straight 2-D copy) into LDS buffer `buf`
     auto issue = [&](int ch, int buf) {
-        inb_mask = 0;
+        inb_mask = 0; s_ch = ch;
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;                                          // scalar
@@ -544,7 +545,9 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
 #pragma unroll
         for (int u = 0; u < UMAX; ++u) {
             const int il = il0 + u * IPP;
-            if (il < IPC) stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, sDump + tid);
+            int c = 0;
+            if (KIND == KAN_BASIS_RELU) { const int item = s_ch * IPC + il; c = item - fastdiv(item, g.divC) * g.C; }
+            if (il < IPC) stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + (il * P) * TP + pxl, TP, sDump + tid, c);
         }
     };
 
@@ -1177,7 +1180,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
             const float xa = x[idx];
             const float xb = same_in ? xa : xn[idx];
             float d[KAN_PMAX];
-            kan_planes<KIND, true>(bs, sTab, xa, xb, d);
+            kan_planes<KIND, true>(bs, sTab, xa, xb, d, c);
             float s_base = 0.f, s_bas = 0.f;
 #pragma unroll
             for (int p = 0; p < KAN_PMAX; ++p) {
@@ -1260,14 +1263,14 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
     // The units this thread gathers with register prefetch belong to FIXED items (the K loop walks pixels, the tile's
     // rows stay): decode them once -- per step only the pixel part of the address changes.  (Was: an LDS read of the
     // item table, three integer multiplies and the unpacking, per unit per step, all of it VALU = matrix time.)
-    int u_off[UPF], u_dr[UPF], u_dt[UPF]; unsigned u_ok = 0;
+    int u_off[UPF], u_dr[UPF], u_dt[UPF], u_c[UPF]; unsigned u_ok = 0;
     const int o_row0 = (o_tile0 + il0) * HoWo;                  // first dz row of this thread (elements)
 #pragma unroll
     for (int u = 0; u < UPF; ++u) {
         const int il = il0 + u * IPP;
         const int it = il < n_items ? sItem[min(il, MAXI - 1)] : -1;
         const int c = it & 0xffff, r = (it >> 16) & 0xff, t = (it >> 24) & 0xff;
-        u_dr[u] = r * g.dh; u_dt[u] = t * g.dw;
+        u_dr[u] = r * g.dh; u_dt[u] = t * g.dw; u_c[u] = it >= 0 ? c : 0;
         u_off[u] = (c * HW + u_dr[u] * g.W + u_dt[u]) * (g.pix_major ? g.B : 1);
         u_ok |= (it >= 0 ? 1u : 0u) << u;
     }
@@ -1321,7 +1324,7 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
             const int il = il0 + u * IPP;
             if (il < n_items) {
                 const int rbase = (item_first + il) * P - k0;
-                stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, sDump + tid);
+                stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> u) & 1u, xa[u], xb[u], dE + rbase, 1, sDump + tid, u_c[u]);
             }
         }
 #pragma unroll 1
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
             const bool inb = unit_addr(sItem[il], s_b, s_hi0, s_wi0, s_pv, idx);
             if (inb) { va = x[idx]; vb = same_in ? va : xn[idx]; }
             const int rbase = (item_first + il) * P - k0;
-            stage_unit<KIND, FAST>(bs, sTab, inb, va, vb, dE + rbase, 1, sDump + tid);
+            stage_unit<KIND, FAST>(bs, sTab, inb, va, vb, dE + rbase, 1, sDump + tid, sItem[il] & 0xffff);
         }
 #pragma unroll
         for (int n = 0; n < ZL; ++n) dZ[il0 + n * IPP] = zr[n];
@@ -1714,7 +1717,8 @@ int check(const KanGeom* g, const KanBasis* b) {
         return fail("activation tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     if (g->x_bstride < (long long)ngroups(g) * g->C * g->H * g->W || g->y_bstride < (long long)ngroups(g) * g->O * g->Ho * g->Wo)
         return fail("batch stride smaller than groups * channels * plane");
-    if (b->kind < 0 || b->kind > KAN_BASIS_FOURIER) return fail("unknown basis kind");
+    if (b->kind < 0 || b->kind > KAN_BASIS_RELU) return fail("unknown basis kind");
+    if (b->kind == KAN_BASIS_RELU && (b->order < 0 || b->order > 2)) return fail("ReLU basis mode (order) must be 0, 1 or 2");
     if (b->kind == KAN_BASIS_FOURIER && (b->n_basis & 1)) return fail("Fourier basis needs an even plane count (cos and sin per frequency)");
     if (b->kind == KAN_BASIS_POLY && (b->n_basis > 11 || b->order < 0 || b->order > 1)) return fail("bad recurrence-basis parameters");
     if (b->act < KAN_ACT_NONE || b->act > KAN_ACT_GELU_TANH) return fail("unknown activation");
@@ -1770,6 +1774,7 @@ DevBasis dev_basis(const KanBasis* b) {
     d.hb = b->act != KAN_ACT_NONE ? 1 : 0; d.P = b->n_basis + d.hb;
     d.p0 = b->p0; d.p1 = b->p1; d.inv_h = 0.f; d.g0 = 0.f; d.gN = 0.f;
     for (int i = 0; i < KAN_MAX_TABLE; ++i) d.tab[i] = b->table[i];
+    d.ctab = b->kind == KAN_BASIS_RELU ? b->chan_table : nullptr;
     if (b->kind == KAN_BASIS_BSPLINE) {
         int nk = b->n_basis + b->order + 1;
         float span = b->table[nk - 1] - b->table[0];
@@ -2152,6 +2157,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!x || !xn || !wp || !z) return fail("null tensor pointer");
+    if (b->kind == KAN_BASIS_RELU && !b->chan_table) return fail("ReLU basis needs the per-channel phase table (chan_table)");
     if (dw_direct(g, b)) {
         DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
         dim3 grid(ceil_div((long long)g->B * g->Ho * g->Wo, 256), ngroups(g));
@@ -2161,6 +2167,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
             case KAN_BASIS_RBF: KAN_DWF(KAN_BASIS_RBF); break;
             case KAN_BASIS_POLY: KAN_DWF(KAN_BASIS_POLY); break;
             case KAN_BASIS_FOURIER: KAN_DWF(KAN_BASIS_FOURIER); break;
+            case KAN_BASIS_RELU: KAN_DWF(KAN_BASIS_RELU); break;
             default: KAN_DWF(KAN_BASIS_CHEBY); break;
         }
 #undef KAN_DWF
@@ -2240,6 +2247,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_FWD_KIND(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_FWD_KIND(KAN_BASIS_FOURIER);
+    else if (b->kind == KAN_BASIS_RELU) KAN_FWD_KIND(KAN_BASIS_RELU);
     else KAN_FWD_KIND(KAN_BASIS_CHEBY);
 #undef KAN_FWD_FAST
 #undef KAN_FWD_KIND
@@ -2253,6 +2261,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !wd || !dx) return fail("null tensor pointer");
+    if (b->kind == KAN_BASIS_RELU && !b->chan_table) return fail("ReLU basis needs the per-channel phase table (chan_table)");
     if (!dxn && x != xn) return fail("dxn is required when xn != x");
     if (dw_direct(g, b)) {
         DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
@@ -2263,6 +2272,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
             case KAN_BASIS_RBF: KAN_DWD(KAN_BASIS_RBF); break;
             case KAN_BASIS_POLY: KAN_DWD(KAN_BASIS_POLY); break;
             case KAN_BASIS_FOURIER: KAN_DWD(KAN_BASIS_FOURIER); break;
+            case KAN_BASIS_RELU: KAN_DWD(KAN_BASIS_RELU); break;
             default: KAN_DWD(KAN_BASIS_CHEBY); break;
         }
 #undef KAN_DWD
@@ -2304,6 +2314,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_BD(KAN_BASIS_FOURIER);
+    else if (b->kind == KAN_BASIS_RELU) KAN_BD(KAN_BASIS_RELU);
     else KAN_BD(KAN_BASIS_CHEBY);
 #undef KAN_BD2
 #undef KAN_BD
@@ -2315,6 +2326,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !dwp) return fail("null tensor pointer");
+    if (b->kind == KAN_BASIS_RELU && !b->chan_table) return fail("ReLU basis needs the per-channel phase table (chan_table)");
     if (dw_direct(g, b)) {
         DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
         dim3 grid(pl.bwd_weight_splits, ngroups(g));
@@ -2324,6 +2336,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
             case KAN_BASIS_RBF: KAN_DWW(KAN_BASIS_RBF); break;
             case KAN_BASIS_POLY: KAN_DWW(KAN_BASIS_POLY); break;
             case KAN_BASIS_FOURIER: KAN_DWW(KAN_BASIS_FOURIER); break;
+            case KAN_BASIS_RELU: KAN_DWW(KAN_BASIS_RELU); break;
             default: KAN_DWW(KAN_BASIS_CHEBY); break;
         }
 #undef KAN_DWW
@@ -2361,6 +2374,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BW_KIND(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_BW_KIND(KAN_BASIS_FOURIER);
+    else if (b->kind == KAN_BASIS_RELU) KAN_BW_KIND(KAN_BASIS_RELU);
     else KAN_BW_KIND(KAN_BASIS_CHEBY);
 #undef KAN_BW_FAST
 #undef KAN_BW_KIND

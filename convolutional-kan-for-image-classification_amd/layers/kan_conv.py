@@ -12,6 +12,7 @@ from typing import Callable, List, Optional, Tuple, Union
 import torch.nn as nn
 
 from .conv_layers import ChebyKANConv2DLayer, FastKANConv2DLayer, KANConv2DLayer
+from .relu_layers import ReLUKANConv2DLayer
 from .poly_layers import (BersnsteinKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, LegendreKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
                           JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 
@@ -191,6 +192,20 @@ def jacobikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gro
                                 base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
 
 
+def relukan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                 dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                 g: int = 5, k: int = 3, train_ab: bool = True, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
+                 norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> ReLUKANConv2DLayer:
+    """layers/kan_conv.py:652-690.  As there, `dilation` only enters the 'same' padding: the layer itself is built with the
+    default dilation 1."""
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return ReLUKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, g=g, k=k, train_ab=train_ab,
+                              groups=groups, padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout,
+                              base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+
+
 def laguerrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
                      dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
                      degree: int = 3, alpha: float = 1.0, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
@@ -242,6 +257,7 @@ CONV_KAN_FACTORY = {
     "JacobiKAN": jacobikan_conv,
     "LaguerreKAN": laguerrekan_conv,
     "LucasKAN": lucaskan_conv,
+    "ReLUKAN": relukan_conv,
     "TaylorKAN": taylorkan_conv,
     "conv": conv,
 }

@@ -76,6 +76,15 @@ def _plan_cached(spec: ConvSpec, B: int, Cg: int, H: int, W: int, Og: int, C_tot
     return g, b, p
 
 
+def _with_phases(basis: L.KanBasis, phases: Optional[torch.Tensor], mode: int = 0) -> L.KanBasis:
+    """Per-call copy of a cached basis struct carrying the device pointer of the ReLU-KAN phase table and the plane mode."""
+    if phases is None:
+        return basis
+    b = L.KanBasis.from_buffer_copy(basis)
+    b.chan_table, b.order = phases.data_ptr(), mode
+    return b
+
+
 def _ptr(t: Optional[torch.Tensor], offset: int = 0) -> C.c_void_p:
     if t is None:
         return C.c_void_p(0)
@@ -144,7 +153,7 @@ def _stack(ws: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
     return ws[0].unsqueeze(0) if len(ws) == 1 else torch.stack(list(ws))
 
 
-def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True):
+def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True, phases=None):
     """Returns (z_slabs [S,B,O,Ho,Wo], (bwd-data weight layout or None, position-major x or None), geom, basis, plan)."""
     lib = L.load()
     B, Ct, H, W = x.shape
@@ -152,6 +161,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     Cg, Og = Ct // G, w_basis[0].shape[0]
     Ot = Og * G
     geom, basis, plan = _plan_cached(spec, B, Cg, H, W, Og, Ct, Ot)
+    basis = _with_phases(basis, phases)
     Ho, Wo = geom.Ho, geom.Wo
     st = _stream(x)
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
@@ -167,7 +177,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     return z, (wd, x_pm), geom, basis, plan
 
 
-def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool):
+def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool, phases=None, mode: int = 0):
     """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list) -- per-group views of stacked gradients."""
     lib = L.load()
     B, Ct, H, W = x.shape
@@ -176,6 +186,7 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     Ot = dz.shape[1]
     Og = Ot // G
     geom, basis, plan = _plan_cached(spec, B, Cg, H, W, Og, Ct, Ot)
+    basis = _with_phases(basis, phases, mode)
     kh, kw = spec.kernel
     st = _stream(x)
     xs = xn if xn is not None else x
@@ -258,6 +269,54 @@ class _KanConv(torch.autograd.Function):
         with torch.cuda.device(x.device):
             dx, dxn, dwb, dws = _conv_backward(ctx.spec, x, xn, packed, dz.contiguous(), need_x, need_xn, need_w)
         return (None, dx if need_x else None, dxn if need_xn else None) + _flat_grads(ctx.spec, dwb, dws)
+
+
+class _KanConvPhased(torch.autograd.Function):
+    """Conv stage of a basis with trainable per-channel parameters (ReLU-KAN: relu_kan_layers.py:118-136).
+    args: spec, x, phases [Cg, 2, n] (phase_low, phase_high per channel), *[w_base_g], *[w_basis_g].
+
+    d phase[c][m][j] = sum_{b,pixel} G_{c,j} * d basis_j / d phase_m, where G = dgrad(dz, W_basis) is never materialised:
+    the sum is regrouped as  sum_{group,o,tap} W_basis[o][c*n+j][tap] * wgrad(d basis / d phase_m, dz)[o][c*n+j][tap],
+    i.e. the weight-gradient kernel run on the parameter-derivative planes, contracted with the weights."""
+
+    @staticmethod
+    def forward(ctx, spec: ConvSpec, x, phases, *weights):
+        x = _require(x, "x")
+        phases = _require(phases, "phases")
+        weights = [_require(w, "weight") for w in weights]
+        w_base, w_basis = _split_weights(spec, weights)
+        G = spec.groups
+        if tuple(phases.shape) != (x.shape[1] // G, 2, spec.n_basis):
+            raise L.KanConvError(f"phase table {tuple(phases.shape)} != (channels per group, 2, n_basis) = {(x.shape[1] // G, 2, spec.n_basis)}")
+        with torch.cuda.device(x.device):
+            z, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, bool(ctx.needs_input_grad[1]), phases)
+            z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
+        ctx.spec = spec
+        ctx.layout = (packed[0] is not None, packed[1] is not None)
+        ctx.save_for_backward(x, phases, *w_basis, *[t for t in packed if t is not None])
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        spec, G = ctx.spec, ctx.spec.groups
+        saved = ctx.saved_tensors
+        x, phases = saved[0], saved[1]
+        w_basis = saved[2:2 + G]
+        packed = _unflatten(ctx.layout, list(saved[2 + G:]))
+        need_x, need_p, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:])
+        dz = dz.contiguous()
+        dph = None
+        with torch.cuda.device(x.device):
+            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w, phases)
+            if need_p:
+                Cg, n = phases.shape[0], spec.n_basis
+                W = torch.stack(list(w_basis)).view(G, -1, Cg, n, spec.kernel[0] * spec.kernel[1])
+                parts = []
+                for mode in (1, 2):
+                    _, _, _, dwm = _conv_backward(spec, x, None, packed, dz, False, False, True, phases, mode)
+                    parts.append((W * torch.stack(list(dwm)).view_as(W)).sum(dim=(0, 1, 4)))
+                dph = torch.stack(parts, dim=1)
+        return (None, dx if need_x else None, dph) + _flat_grads(spec, dwb, dws)
 
 
 def _cat(ts: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
@@ -380,6 +439,13 @@ def kan_conv(spec: ConvSpec, x: torch.Tensor, xn: Optional[torch.Tensor], w_base
              w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     return _KanConv.apply(spec, x, xn, *ws)
+
+
+def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_base: Sequence[torch.Tensor],
+                    w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Conv stage of the ReLU-KAN basis; `phases` = [channels per group, 2, n_basis] (low, high), differentiable."""
+    ws = (list(w_base) if spec.has_base else []) + list(w_basis)
+    return _KanConvPhased.apply(spec, x, phases, *ws)
 
 
 def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Tensor], w_basis: Sequence[torch.Tensor],

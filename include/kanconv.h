@@ -33,7 +33,7 @@ extern "C" {
 #define KAN_MAX_TABLE  32   /* knots (B-spline) or centres (RBF) */
 
 /* basis families */
-enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3, KAN_BASIS_FOURIER = 4 };
+enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3, KAN_BASIS_FOURIER = 4, KAN_BASIS_RELU = 5 };
 /* base-branch activations; KAN_ACT_NONE = layer has no base branch (ChebyKAN) */
 enum { KAN_ACT_NONE = -1, KAN_ACT_IDENTITY = 0, KAN_ACT_GELU = 1, KAN_ACT_SILU = 2, KAN_ACT_RELU = 3,
        KAN_ACT_TANH = 4, KAN_ACT_SIGMOID = 5, KAN_ACT_GELU_TANH = 6 };
@@ -63,12 +63,20 @@ typedef struct KanGeom {
  *              T_k = (table[3k-3]*t + table[3k-2]) * T_{k-1} + table[3k-1] * T_{k-2} for k >= 2;  n_basis <= 11
  *   Fourier  : n_basis = 2*grid_size planes cos(k x), k = 1..grid_size, then sin(k x)
  *              (layers/fourier_kan_layers.py:163-187)
+ *   ReLU     : n_basis = g + k planes  (r * relu(x - lo[c][j]) * relu(hi[c][j] - x))^2, p0 = r = 4 g^2 / (k+1)^2
+ *              (layers/relu_kan_layers.py:118-136).  The phases are PER CHANNEL and trainable, so they live in device
+ *              memory: chan_table[c][0][j] = phase_low, chan_table[c][1][j] = phase_high, c = channel inside its group
+ *              (the reference shares one phase tensor between the groups).  `order` selects what the non-derivative
+ *              planes hold: 0 the basis; 1 / 2 its derivative w.r.t. phase_low / phase_high (base plane zero), so
+ *              that kan_conv_bwd_weight yields the factor of the phase gradient,
+ *              d phase[c][j] = sum_{o,tap} W[o][c*n+j][tap] * dW_mode[o][c*n+j][tap].
  * `act` is the base-branch activation (KAN_ACT_NONE: no base branch, no base weight).
  * Planes per channel P = n_basis + (act != KAN_ACT_NONE); P <= KAN_MAX_PLANES. */
 typedef struct KanBasis {
     int kind, n_basis, order, act;
     float p0, p1;
     float table[KAN_MAX_TABLE];
+    const float* chan_table;      /* device pointer, KAN_BASIS_RELU only: [C][2][n_basis] floats; NULL otherwise */
 } KanBasis;
 
 /* Launch plan for one geometry: split counts and workspace sizes (bytes). */

@@ -261,6 +261,31 @@ def fourierkan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_fourier: Sequence[T
     return _per_group(x, groups, one)
 
 
+def relukan_basis(x: Tensor, phase_low: Tensor, phase_high: Tensor, r: float) -> Tensor:
+    """[B, C, g+k, H, W]: (relu(x - lo) * relu(hi - x) * r)^2, phases of shape (1, C, g+k, 1, 1)  (relu_kan_layers.py:126-131)."""
+    xe = x.unsqueeze(2)
+    q = torch.relu(xe - phase_low) * torch.relu(phase_high - xe) * r
+    return q * q
+
+
+def relukan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_relukan: Sequence[Tensor], phase_low: Tensor, phase_high: Tensor, *,
+                   g: int, k: int, act: Optional[Callable[[Tensor], Tensor]], stride=1, padding=0, dilation=1, groups: int = 1,
+                   norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
+    """act(norm(conv(act(x), W_b) + conv(relukan_basis(x), W_r))), one phase pair shared by all groups
+    (relu_kan_layers.py:118-146)."""
+    r = 4 * g * g / ((k + 1) * (k + 1))
+
+    def one(xg, gi):
+        a = xg if act is None else act(xg)
+        z = _conv(a, w_base[gi], stride, padding, dilation) + _conv(relukan_basis(xg, phase_low, phase_high, r).flatten(1, 2),
+                                                                    w_relukan[gi], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[gi](z)
+        return n if act is None else act(n)
+    return _per_group(x, groups, one)
+
+
 def legendrekan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, *, degree: int, stride=1, padding=0, dilation=1,
                        groups: int = 1, norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None,
                        pre_norm_out: Optional[list] = None) -> Tensor:

@@ -153,9 +153,29 @@ CASES_1D = [
 ]
 
 
+# ---- ReLU-KAN (relu_kan_layers.py): trainable per-channel phases, perturbed so that channels differ; own seed range
+RELU_CASES = [
+    C("relu", "tiny", 2, 3, 4, 8, 8),
+    C("relu", "g3k2_groups2", 2, 4, 6, 7, 5, groups=2, act="gelu", xs=1.5, extra={"g": 3, "k": 2}),
+    C("relu", "s2_affine_fixed", 3, 4, 6, 9, 9, s=2, norm_kwargs={"affine": True}, extra={"train_ab": False}),
+    C("relu", "k5d2_x3", 2, 3, 5, 11, 11, k=5, p=4, d=2, xs=3.0, act="none"),
+    C("relu", "wide", 3, 20, 40, 6, 6, extra={"g": 4, "k": 3}),
+    C("relu", "depthwise_bn", 3, 4, 8, 8, 8, groups=4, norm="bn"),
+    C("relu", "1d_k3s2", 2, 4, 6, 1, 33, ndim=1, s=2),        # (the 1-D shim drops base_activation: relu_kan_layers.py:183-187)
+]
+
+
 def build_ref(c):
     kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
     one_d = c.get("ndim", 2) == 1
+    if c["kind"] == "relu":
+        kw.update(c.get("norm_kwargs", {}))
+        kw.update(c.get("extra", {}))
+        if "norm" in c:
+            kw["norm_layer"] = NORMS[c["norm"]]
+        if "act" in c:
+            kw["base_activation"] = ACTS[c["act"]]
+        return (REF_LAYERS.ReLUKANConv1DLayer if one_d else REF_LAYERS.ReLUKANConv2DLayer)(c["C"], c["O"], **kw)
     if c["kind"] in POLY_FAMILIES:
         kw.update(c.get("norm_kwargs", {}))
         kw.update(c.get("extra", {}))
@@ -200,7 +220,7 @@ def oracle_forward(c, layer, x, pre):
 
 def oracle_forward_1d(c, layer, x, pre):
     """1-D layer == the 2-D oracle on [B, C, 1, L] with (1, k) kernels; norms act on the squeezed tensor."""
-    sd = {n: p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
+    sd = {n: p.unsqueeze(-1) if n.startswith("phase") else p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
     norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(c["groups"])]
     geo = dict(stride=(1, c["s"]), padding=(0, c["p"]), dilation=(1, c["d"]), groups=c["groups"])
     pre4 = []
@@ -227,6 +247,10 @@ def oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
         return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)],
                                 [sd[f"spline_conv.{g}.weight"] for g in range(G)],
                                 centres=centres, denom=denom, act=act, norm=norms, **geo)
+    if c["kind"] == "relu":
+        return O.relukan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"relukan_conv.{g}.weight"] for g in range(G)],
+                                sd["phase_low"], sd["phase_high"], g=layer.g, k=layer.k, act=ACT_FN[c.get("act", "silu")], norm=norms,
+                                pre_norm_out=pre, **geo)
     if c["kind"] == "jacobi":
         return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree,
                                   a=layer.a, b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)
@@ -256,6 +280,9 @@ def run_case(idx, c):
         for j, (n, p) in enumerate(layer.named_parameters()):
             if "prelus" in n:
                 p.fill_(0.25 if j % 2 else 0.1)
+            elif n.startswith("phase"):                         # ReLU-KAN phases: channels and planes drift apart as in training
+                d = torch.empty(p.shape); det_fill(d, idx * 31 + j, 0.07)      # (the reference's Parameter is an expand() view whose
+                p.data = p.data.clone() + d                                    #  channels alias one row: give it its own memory)
             elif "layer_norm" in n and n.endswith("weight"):
                 det_fill(p, idx * 31 + j, 0.5); p.add_(1.0)
             elif "layer_norm" in n:
@@ -273,7 +300,7 @@ def run_case(idx, c):
 
     pre_ref = []
     hooks = []
-    if c["kind"] in ("bspline", "cheby") or c["kind"] in POLY_FAMILIES:
+    if c["kind"] in ("bspline", "cheby", "relu") or c["kind"] in POLY_FAMILIES:
         for g in range(c["groups"]):
             hooks.append(layer.layer_norm[g].register_forward_pre_hook(lambda m, a: pre_ref.append(a[0].detach().clone())))
     y = layer(x)
@@ -433,6 +460,12 @@ def cases_1d():
         print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 
 
+def relu_cases():
+    for i, c in enumerate(RELU_CASES):
+        worst, sz = run_case(7000 + i, c)
+        print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 def mlp_cases():
     for i, c in enumerate(MLP_CASES):
         worst, sz = run_mlp_case(i, c)
@@ -499,6 +532,8 @@ def main():
         return poly_cases()
     if "--1d-only" in sys.argv:
         return cases_1d()
+    if "--relu-only" in sys.argv:
+        return relu_cases()
     total = 0
     for i, c in enumerate(CASES):
         worst, sz = run_case(i, c)
@@ -508,6 +543,7 @@ def main():
     mlp_cases()
     poly_cases()
     cases_1d()
+    relu_cases()
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)

@@ -24,6 +24,11 @@ def layer_kwargs(c):
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:
         kw["norm_layer"] = NORMS[c["norm"]]
+    if c["kind"] == "relu":
+        kw.update(c.get("extra", {}))
+        if "act" in c:
+            kw["base_activation"] = ACTS[c["act"]]
+        return kw
     if c["kind"] in POLY:
         kw.update(c.get("extra", {}))
         kw["grid_size" if c["kind"] == "fourier" else "degree"] = c["degree"]
@@ -47,6 +52,8 @@ def layer_kwargs(c):
 
 def build_layer(c):
     import convkan_amd as K
+    if c["kind"] == "relu":
+        return (K.ReLUKANConv1DLayer if c.get("ndim", 2) == 1 else K.ReLUKANConv2DLayer)(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] in POLY:
         return getattr(K, POLY[c["kind"]])(c["C"], c["O"], **layer_kwargs(c))
     if c.get("ndim", 2) == 1:
@@ -65,7 +72,7 @@ def oracle_forward(c, layer, x, pre=None):
     """Oracle forward with `layer`'s parameters (any object exposing the reference's attribute names)."""
     G = c["groups"]
     if c.get("ndim", 2) == 1:          # 1-D layer == the 2-D oracle on [B, C, 1, L] with (1, k) kernels
-        sd = {n: p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
+        sd = {n: p.unsqueeze(-1) if n.startswith("phase") else p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
         norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(G)]
         geo = dict(stride=(1, c["s"]), padding=(0, c["p"]), dilation=(1, c["d"]), groups=G)
         pre4 = [] if pre is not None else None
@@ -89,6 +96,10 @@ def _oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
         centres, denom = O.rbf_grid(layer.grid_size, layer.grid_range)
         return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"spline_conv.{g}.weight"] for g in range(G)],
                                 centres=centres.to(x.device), denom=denom, act=ACT_FN[c.get("act", "silu")], norm=norms, **geo)
+    if c["kind"] == "relu":
+        return O.relukan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"relukan_conv.{g}.weight"] for g in range(G)],
+                                sd["phase_low"], sd["phase_high"], g=layer.g, k=layer.k, act=ACT_FN[c.get("act", "silu")], norm=norms,
+                                pre_norm_out=pre, **geo)
     if c["kind"] == "jacobi":
         return O.jacobikan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], degree=layer.degree, a=layer.a,
                                   b=layer.b, act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **geo)

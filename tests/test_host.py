@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.KanGeom) == 16 * 4 + 16              # 16 ints (incl. groups), 2 x int64
     assert L.KanGeom.groups.offset == 60 and L.KanGeom.x_bstride.offset == 64
-    assert ctypes.sizeof(L.KanBasis) == 4 * 4 + 2 * 4 + 32 * 4
+    assert ctypes.sizeof(L.KanBasis) == 4 * 4 + 2 * 4 + 32 * 4 + 8 and L.KanBasis.chan_table.offset == 152      # + the phase-table pointer
     assert ctypes.sizeof(L.KanPlan) == 14 * 4 + 5 * 8
 
 
@@ -171,7 +171,17 @@ def test_polynomial_family_surface():
 def test_factory_signatures_and_same_padding():
     F = K.CONV_KAN_FACTORY
     poly = {"BesselKAN", "FibonacciKAN", "GegenbauerKAN", "HermiteKAN", "JacobiKAN", "LaguerreKAN", "LucasKAN", "TaylorKAN"}
-    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "conv"} | poly
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "ReLUKAN", "conv"} | poly
+    rl = F["ReLUKAN"](4, 6, 3, groups=2, dilation=2)             # kan_conv.py:652-690; relu_kan_layers.py:41-116
+    assert (rl.padding, rl.dilation, rl.g, rl.k, rl.r, rl.train_ab) == (2, 1, 5, 3, 6.25, True) and isinstance(rl.base_activation, nn.GELU)
+    assert list(rl.state_dict()) == ["phase_low", "phase_high", "base_conv.0.weight", "base_conv.1.weight", "relukan_conv.0.weight",
+                                     "relukan_conv.1.weight"]
+    assert rl.phase_low.shape == (1, 2, 8, 1, 1) and rl.relukan_conv[0].weight.shape == (3, 16, 3, 3)
+    assert torch.equal(rl.phase_low[0, 1, :, 0, 0], torch.arange(-3, 5) / 5) and torch.equal(rl.phase_high, rl.phase_low + 4 / 5)
+    assert not F["ReLUKAN"](4, 6, 3, train_ab=False).phase_low.requires_grad
+    assert isinstance(K.ReLUKANConv2DLayer(4, 6, 3).base_activation, nn.SiLU) and K.ReLUKANConv1DLayer(4, 6, 3).phase_high.shape == (1, 4, 8, 1)
+    assert isinstance(K.ReLUKANConv1DLayer(4, 6, 3, base_activation=nn.GELU).base_activation, nn.SiLU)       # dropped, as in the reference
+    assert K.ReLUKANConv2DLayer(4, 6, 3).conv_spec().kind == L.BASIS_RELU
     lg = F["LegendreKAN"](4, 6, 3, dilation=2)
     assert (lg.padding, lg.dilation, lg.degree) == (2, 2, 3) and isinstance(lg.base_activation, nn.SiLU)
     assert list(inspect.signature(F["LegendreKAN"]).parameters)[3] == "degree"

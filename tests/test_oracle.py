@@ -25,12 +25,15 @@ class _Params(nn.Module):
         self.degree = c.get("degree", 3)
         names = sorted({k[3:].split(".")[0] for k in d if k.startswith("sd.")})
         for n in names:
-            if n in ("base_conv", "spline_conv", "poly_conv", "fourier_conv", "prelus"):
+            if n in ("base_conv", "spline_conv", "poly_conv", "fourier_conv", "relukan_conv", "prelus"):
                 lst = nn.ParameterList([nn.Parameter(torch.from_numpy(d[f"sd.{n}.{g}.weight"])) for g in range(G)])
                 setattr(self, n + "_p", lst)
         if "sd.poly_weights" in d:                                # JacobiKAN: one [G, O/G, C/G*(deg+1), k, k] parameter
             self.poly_weights = nn.Parameter(torch.from_numpy(d["sd.poly_weights"]))
             self.a, self.b = c.get("extra", {}).get("a"), c.get("extra", {}).get("b")
+        if "sd.phase_low" in d:                                   # ReLU-KAN: per-channel phases, g / k from the case
+            self.phase_low, self.phase_high = (nn.Parameter(torch.from_numpy(d["sd.phase_" + w])) for w in ("low", "high"))
+            self.g, self.k = c.get("extra", {}).get("g", 5), c.get("extra", {}).get("k", 3)
         norm_cls = NORMS[c.get("norm", "in")] if c.get("ndim", 2) == 2 else nn.InstanceNorm1d
         nch = (c["C"] if c["kind"] == "rbf" else c["O"]) // G
         kw = {k: v for k, v in c.get("norm_kwargs", {}).items()}

@@ -16,3 +16,5 @@ from .layers.poly_layers import (LegendreKANConv2DLayer, BersnsteinKANConv2DLaye
 from .layers.conv_layers import KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv1DLayer   # noqa: F401,E402
 from .layers.relu_layers import ReLUConvNDLayer, ReLUKANConv2DLayer, ReLUKANConv1DLayer   # noqa: F401,E402
 from .layers.kan_conv import relukan_conv   # noqa: F401,E402
+from .optim import FusedAdamW   # noqa: F401,E402
+from .train import train_step, train_model_generic   # noqa: F401,E402

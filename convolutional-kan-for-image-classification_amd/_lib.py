@@ -36,7 +36,7 @@ class KanPlan(C.Structure):
 
 
 # every symbol include/kanconv.h declares, with its argument types
-_P, _I, _LL, _F = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+_P, _I, _LL, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 _GP, _BP = C.POINTER(KanGeom), C.POINTER(KanBasis)
 SIGNATURES = {
     "kan_version": (C.c_char_p, []),
@@ -51,6 +51,8 @@ SIGNATURES = {
     "kan_slab_reduce": (_I, [_P, _I, _LL, _P, _I, _I, _I, _LL, _P]),
     "kan_instnorm_prelu_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _F, _I, _P]),
     "kan_instnorm_prelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _I, _P]),
+    "kan_adamw_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _F, _P]),
+    "kan_adamw_step_segments": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _D, _D, _I, _F, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

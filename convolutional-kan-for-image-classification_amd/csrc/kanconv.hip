@@ -17,6 +17,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
+#include <cstdint>
 #include "kanconv.h"
 #include "kan_device.h"
 
@@ -2071,6 +2073,72 @@ int group_lanes(int HW) {          // (more elements per lane was measured: no g
     return g;
 }
 
+// ============================================================================ optimizer step
+// AdamW over one flat fp32 block (generic_train.py:24 optim.AdamW(lr, weight_decay); formulas and their order as
+// torch/optim/adamw.py's single-tensor path):  p *= 1 - lr wd;  m = m + (g - m)(1 - b1);  v = v b2 + (1 - b2) g g;
+// p += -(lr / bc1) * (m / (sqrt(v) / sqrt(bc2) + eps)).  Pure HBM traffic: 16 B read + 12 B written per element, so the
+// kernel is float4 loads/stores over a grid-stride loop with correctly rounded sqrt / divide (free at this intensity).
+struct AdamArgs { float decay, w1, b2, w2, gscale, inv_bc2_sqrt, eps, neg_step; };
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    g *= a.gscale;
+    p *= a.decay;
+    m = m + (g - m) * a.w1;
+    v = v * a.b2 + a.w2 * g * g;
+    const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+    p += a.neg_step * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, long long n, AdamArgs a) {
+    const long long n4 = n >> 2;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+        adam1(P.x, G.x, M.x, V.x, a); adam1(P.y, G.y, M.y, V.y, a); adam1(P.z, G.z, M.z, V.z, a); adam1(P.w, G.w, M.w, V.w, a);
+        ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+    }
+    const long long t = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x;      // < 4 tail elements
+    if (t < n) adam1(p[t], g[t], m[t], v[t], a);
+}
+
+// The same update over SEGMENTS of the flat block whose gradients live wherever autograd (or the all-reduce bucket) left
+// them: workgroup b owns chunk b = elements [start, start + chunk) of segment chunk_seg[b]; a segment whose gradient
+// pointer is null is skipped, as torch skips parameters without .grad.  Nothing is copied or zeroed per step.
+__global__ __launch_bounds__(256) void k_adamw_seg(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                                   const unsigned long long* __restrict__ seg_grad, const long long* __restrict__ seg_off,
+                                                   const int* __restrict__ seg_n, const int* __restrict__ chunk_seg,
+                                                   const int* __restrict__ chunk_start, const float* __restrict__ seg_bias, int chunk,
+                                                   AdamArgs a) {
+    const int sg = chunk_seg[blockIdx.x], start = chunk_start[blockIdx.x];
+    const float* g = (const float*)seg_grad[sg];
+    if (!g) return;
+    if (seg_bias) { a.neg_step = seg_bias[2 * sg]; a.inv_bc2_sqrt = seg_bias[2 * sg + 1]; }     // per-parameter step counts
+    const int n = min(chunk, seg_n[sg] - start);
+    const long long off = seg_off[sg] + start;
+    p += off; m += off; v += off; g += start;
+    if ((((uintptr_t)g) & 15u) == 0) {                          // p / m / v chunks are 16-byte aligned by construction
+        for (int i = threadIdx.x; i < (n >> 2); i += 256) {
+            float4 P = ((float4*)p)[i], G = ((const float4*)g)[i], M = ((float4*)m)[i], V = ((float4*)v)[i];
+            adam1(P.x, G.x, M.x, V.x, a); adam1(P.y, G.y, M.y, V.y, a); adam1(P.z, G.z, M.z, V.z, a); adam1(P.w, G.w, M.w, V.w, a);
+            ((float4*)p)[i] = P; ((float4*)m)[i] = M; ((float4*)v)[i] = V;
+        }
+        const int t = (n & ~3) + threadIdx.x;
+        if (t < n) adam1(p[t], g[t], m[t], v[t], a);
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) adam1(p[i], g[i], m[i], v[i], a);
+    }
+}
+
+AdamArgs adam_args(double lr, double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale) {
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    AdamArgs a;
+    a.decay = (float)(1.0 - lr * weight_decay);                 // hyper-parameters arrive as doubles (Python floats): 1 - beta2 formed
+    a.w1 = (float)(1.0 - beta1); a.b2 = (float)beta2; a.w2 = (float)(1.0 - beta2);      // from a float beta2 is off by 1e-5 relative
+    a.gscale = grad_scale; a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2)); a.eps = (float)eps; a.neg_step = (float)(-lr / bc1);
+    return a;
+}
+
 }  // namespace
 
 // ============================================================================ C ABI
@@ -2421,6 +2489,33 @@ int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, c
         default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
     }
     return launch_ok("instnorm_bwd");
+}
+
+int kan_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v) return fail("null tensor pointer");
+    if (n < 0 || step < 1) return fail("adamw: n must be >= 0 and step >= 1");
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) return fail("adamw: blocks must be 16-byte aligned");
+    if (n == 0) return 0;
+    const AdamArgs a = adam_args(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    long long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;                  // 16 workgroups per CU, grid-stride beyond
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_adamw, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, a);
+    return launch_ok("adamw");
+}
+
+int kan_adamw_step_segments(float* p, float* m, float* v, const unsigned long long* seg_grad, const long long* seg_off, const int* seg_n,
+                            const int* chunk_seg, const int* chunk_start, const float* seg_bias, int n_chunks, int chunk_elems, double lr,
+                            double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale, void* stream) {
+    if (!p || !m || !v || !seg_grad || !seg_off || !seg_n || !chunk_seg || !chunk_start) return fail("null tensor pointer");
+    if (n_chunks < 0 || step < 1 || chunk_elems < 4 || (chunk_elems & 3)) return fail("adamw: bad chunk table or step");
+    if (((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) & 15u) return fail("adamw: blocks must be 16-byte aligned");
+    if (n_chunks == 0) return 0;
+    const AdamArgs a = adam_args(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    hipLaunchKernelGGL(k_adamw_seg, dim3((unsigned)n_chunks), dim3(256), 0, (hipStream_t)stream, p, m, v, seg_grad, seg_off, seg_n, chunk_seg,
+                       chunk_start, seg_bias, chunk_elems, a);
+    return launch_ok("adamw_seg");
 }
 
 }  // extern "C"

@@ -186,6 +186,28 @@ int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, c
                            float* dz, float* dgamma, float* dbeta, float* dprelu,
                            int B, int Cn, int HW, long long bstride, int prelu_span, void* stream);
 
+/* One AdamW step over a flat fp32 block of n elements, in place (p, m = exp_avg, v = exp_avg_sq; g is read only and
+ * multiplied by grad_scale first).  Replaces the per-tensor update loop of torch.optim.AdamW as the reference builds it
+ * (generic_train.py:24 `optim.AdamW(model.parameters(), lr, weight_decay)`, stepped once per batch: evaluations.py train()),
+ * same formulas in the same order, amsgrad / maximize off:
+ *   p *= 1 - lr*weight_decay;  m += (g - m)(1 - beta1);  v = v*beta2 + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `step` counts from 1.  The four blocks must be 16-byte aligned.  HBM-bound: 28 bytes per element. */
+int kan_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int step, float grad_scale, void* stream);
+
+/* The same step with the gradients left where autograd (or an all-reduce bucket) wrote them.  p / m / v are flat blocks
+ * holding n_seg segments (one per parameter); segment s covers elements [seg_off[s], seg_off[s] + seg_n[s]) and reads its
+ * gradient from the device address seg_grad[s] (0 = no gradient this step: the segment is skipped, as torch skips it).
+ * Workgroup b updates elements [chunk_start[b], chunk_start[b] + chunk_elems) of segment chunk_seg[b]; the caller builds
+ * the chunk table once per layout (seg_off and chunk_start multiples of 4 elements, chunk_elems a multiple of 4).  All
+ * tables are DEVICE arrays; only seg_grad changes between steps.  torch counts steps PER PARAMETER (one that had no
+ * gradient for a while is bias-corrected with its own count): seg_bias, if not NULL, holds per segment
+ * { -lr / (1 - beta1^step_s), 1 / sqrt(1 - beta2^step_s) } and overrides the values derived from `step`. */
+int kan_adamw_step_segments(float* p, float* m, float* v, const unsigned long long* seg_grad, const long long* seg_off, const int* seg_n,
+                            const int* chunk_seg, const int* chunk_start, const float* seg_bias, int n_chunks, int chunk_elems, double lr,
+                            double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -132,6 +132,9 @@ class FusedAdamW(torch.optim.Optimizer):
                                                     group["weight_decay"], group["step"], 1.0,
                                                     C.c_void_p(torch.cuda.current_stream(blk.device).cuda_stream)), "kan_adamw_step_segments")
             del keep
+            for p, a in zip(flat["params"], ptrs):                         # the kernel wrote through raw pointers: tell autograd (and
+                if a:                                                      # the packed-weight cache of ops.py) that the values changed
+                    torch.autograd.graph.increment_version(p)
         return loss
 
     def state_dict(self):

@@ -120,3 +120,32 @@ def test_train_model_generic_reduces_loss(gpu_lib):
     x, t = torch.randn(8, 3, 32, 32), torch.randint(0, 10, (8,))
     hist = K.train_model_generic(m, [(x, t)] * 3, device="cuda", learning_rate=1e-3, weight_decay=1e-4, gamma=0.8, epochs=4)
     assert len(hist) == 4 and hist[-1] < hist[0] and all(h == h for h in hist)
+
+
+@pytest.mark.gpu
+def test_packed_weight_cache_follows_every_weight_update(gpu_lib):
+    """No-grad forwards reuse the packed weights (ops._PACK_CACHE); an in-place update -- torch's or FusedAdamW's raw-pointer
+    kernel -- must invalidate them.  The grad-enabled forward never uses the cache and serves as the check."""
+    from convkan_amd import ops
+    torch.manual_seed(0)
+    layer = K.KANConv2DLayer(8, 128, 3, padding=1).cuda()
+    x = torch.randn(4, 8, 8, 8, device="cuda")
+    ops._PACK_CACHE.clear()
+    with torch.no_grad():
+        y0 = layer(x)
+        n_entries = len(ops._PACK_CACHE)
+        y1 = layer(x)
+    assert n_entries == 1 and len(ops._PACK_CACHE) == 1 and torch.equal(y0, y1)
+    assert torch.equal(layer(x).detach(), y0) and len(ops._PACK_CACHE) == 1          # the training forward neither reads nor fills it
+    with torch.no_grad():
+        layer.spline_conv[0].weight.mul_(1.5)                                        # version counter moves
+        y2 = layer(x)
+    assert not torch.equal(y2, y0) and torch.equal(layer(x).detach(), y2)
+    opt = K.FusedAdamW(layer.parameters(), lr=1e-2)
+    with torch.no_grad():
+        y3 = layer(x)                                                                # cached against the flattened parameters
+    layer(x).square().mean().backward()
+    opt.step()
+    with torch.no_grad():
+        y4 = layer(x)
+    assert not torch.equal(y4, y3) and torch.equal(layer(x).detach(), y4)

@@ -18,3 +18,5 @@ from .layers.relu_layers import ReLUConvNDLayer, ReLUKANConv2DLayer, ReLUKANConv
 from .layers.kan_conv import relukan_conv   # noqa: F401,E402
 from .optim import FusedAdamW   # noqa: F401,E402
 from .train import train_step, train_model_generic   # noqa: F401,E402
+from .layers.gram_layers import GRAMKANConvNDLayer, GRAMKANConv2DLayer   # noqa: F401,E402
+from .layers.kan_conv import gramkan_conv   # noqa: F401,E402

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libkanconv.so")
 
 KAN_MAX_PLANES = 16
 KAN_MAX_TABLE = 32
-BASIS_BSPLINE, BASIS_RBF, BASIS_CHEBY, BASIS_POLY, BASIS_FOURIER, BASIS_RELU = 0, 1, 2, 3, 4, 5
+BASIS_BSPLINE, BASIS_RBF, BASIS_CHEBY, BASIS_POLY, BASIS_FOURIER, BASIS_RELU, BASIS_GRAM = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_IDENTITY, ACT_GELU, ACT_SILU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_TANH = -1, 0, 1, 2, 3, 4, 5, 6
 
 

@@ -16,7 +16,7 @@ struct DevBasis {            // by-value kernel argument
     float p0, p1, inv_h;
     float g0, gN;            // B-spline: first / last knot (the span outside which every basis is zero)
     float tab[KAN_MAX_TABLE];
-    const float* ctab;       // ReLU-KAN: per-channel phases [C][2][nb] in device memory
+    const float* ctab;       // device-memory parameters: ReLU-KAN per-channel phases [C][2][nb]; Gram coefficients [nb]
 };
 
 // ---------------------------------------------------------------- activations
@@ -195,6 +195,29 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
                 const float q = x1 * x2 * r;
                 const float q2 = 2.0f * q * r;
                 v[p] = mode == 0 ? q * q : mode == 1 ? -(q2 * x2) : mode == 2 ? q2 * x1 : q2 * (x2 - x1);
+            }
+        }
+    } else if (KIND == KAN_BASIS_GRAM) {
+        // gram_kan_layers.py:156-182: planes act(P_k(t)), t = tanh x, P_0 = 1, P_1 = t, P_k = t P_{k-1} - c_k P_{k-2} with the
+        // trainable c_k in device memory.  Alongside: D_k = dP_k/dt and, for mode m >= 1, Q_k = dP_k/dc_{m+1}
+        // (Q_k = t Q_{k-1} - c_k Q_{k-2} - [k == m+1] P_{k-2}).
+        const float* cf = bs.ctab;
+        const float t = tanhf(xb), chain = 1.0f - t * t;
+        const int mode = DERIV ? 0 : bs.order;
+        if (hb && mode != 0) v[0] = 0.f;
+        float Pm = 1.f, Pc = t, Dm = 0.f, Dc = 1.f, Qm = 0.f, Qc = 0.f;
+#pragma unroll
+        for (int p = 0; p < KAN_PMAX; ++p) {
+            const int k = p - hb;
+            if (k >= 0 && k < bs.nb) {
+                const float P = k == 0 ? 1.f : Pc, D = k == 0 ? 0.f : Dc, Q = k == 0 ? 0.f : Qc;
+                v[p] = DERIV ? kan_act_grad(bs.act, P) * D * chain : mode == 0 ? kan_act(bs.act, P) : kan_act_grad(bs.act, P) * Q;
+                if (k >= 1 && k + 1 < bs.nb) {
+                    const float c = cf[k + 1];
+                    const float Pn = t * Pc - c * Pm, Dn = Pc + t * Dc - c * Dm;
+                    const float Qn = t * Qc - c * Qm - (k + 1 == mode + 1 ? Pm : 0.f);
+                    Pm = Pc; Pc = Pn; Dm = Dc; Dc = Dn; Qm = Qc; Qc = Qn;
+                }
             }
         }
     } else if (KIND == KAN_BASIS_POLY) {

@@ -1719,7 +1719,9 @@ int check(const KanGeom* g, const KanBasis* b) {
         return fail("activation tensors must be smaller than 2 GiB (32-bit buffer offsets)");
     if (g->x_bstride < (long long)ngroups(g) * g->C * g->H * g->W || g->y_bstride < (long long)ngroups(g) * g->O * g->Ho * g->Wo)
         return fail("batch stride smaller than groups * channels * plane");
-    if (b->kind < 0 || b->kind > KAN_BASIS_RELU) return fail("unknown basis kind");
+    if (b->kind < 0 || b->kind > KAN_BASIS_GRAM) return fail("unknown basis kind");
+    if (b->kind == KAN_BASIS_GRAM && (b->order < 0 || b->order >= b->n_basis || b->n_basis < 2 || b->act == KAN_ACT_NONE))
+        return fail("Gram basis needs degree >= 1, an activation, and a mode (order) in 0..degree-1");
     if (b->kind == KAN_BASIS_RELU && (b->order < 0 || b->order > 2)) return fail("ReLU basis mode (order) must be 0, 1 or 2");
     if (b->kind == KAN_BASIS_FOURIER && (b->n_basis & 1)) return fail("Fourier basis needs an even plane count (cos and sin per frequency)");
     if (b->kind == KAN_BASIS_POLY && (b->n_basis > 11 || b->order < 0 || b->order > 1)) return fail("bad recurrence-basis parameters");
@@ -1776,7 +1778,7 @@ DevBasis dev_basis(const KanBasis* b) {
     d.hb = b->act != KAN_ACT_NONE ? 1 : 0; d.P = b->n_basis + d.hb;
     d.p0 = b->p0; d.p1 = b->p1; d.inv_h = 0.f; d.g0 = 0.f; d.gN = 0.f;
     for (int i = 0; i < KAN_MAX_TABLE; ++i) d.tab[i] = b->table[i];
-    d.ctab = b->kind == KAN_BASIS_RELU ? b->chan_table : nullptr;
+    d.ctab = (b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) ? b->chan_table : nullptr;
     if (b->kind == KAN_BASIS_BSPLINE) {
         int nk = b->n_basis + b->order + 1;
         float span = b->table[nk - 1] - b->table[0];
@@ -2225,7 +2227,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!x || !xn || !wp || !z) return fail("null tensor pointer");
-    if (b->kind == KAN_BASIS_RELU && !b->chan_table) return fail("ReLU basis needs the per-channel phase table (chan_table)");
+    if ((b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) && !b->chan_table) return fail("ReLU / Gram bases need their device parameter table (chan_table)");
     if (dw_direct(g, b)) {
         DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
         dim3 grid(ceil_div((long long)g->B * g->Ho * g->Wo, 256), ngroups(g));
@@ -2236,6 +2238,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
             case KAN_BASIS_POLY: KAN_DWF(KAN_BASIS_POLY); break;
             case KAN_BASIS_FOURIER: KAN_DWF(KAN_BASIS_FOURIER); break;
             case KAN_BASIS_RELU: KAN_DWF(KAN_BASIS_RELU); break;
+            case KAN_BASIS_GRAM: KAN_DWF(KAN_BASIS_GRAM); break;
             default: KAN_DWF(KAN_BASIS_CHEBY); break;
         }
 #undef KAN_DWF
@@ -2316,6 +2319,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     else if (b->kind == KAN_BASIS_POLY) KAN_FWD_KIND(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_FWD_KIND(KAN_BASIS_FOURIER);
     else if (b->kind == KAN_BASIS_RELU) KAN_FWD_KIND(KAN_BASIS_RELU);
+    else if (b->kind == KAN_BASIS_GRAM) KAN_FWD_KIND(KAN_BASIS_GRAM);
     else KAN_FWD_KIND(KAN_BASIS_CHEBY);
 #undef KAN_FWD_FAST
 #undef KAN_FWD_KIND
@@ -2329,7 +2333,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !wd || !dx) return fail("null tensor pointer");
-    if (b->kind == KAN_BASIS_RELU && !b->chan_table) return fail("ReLU basis needs the per-channel phase table (chan_table)");
+    if ((b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) && !b->chan_table) return fail("ReLU / Gram bases need their device parameter table (chan_table)");
     if (!dxn && x != xn) return fail("dxn is required when xn != x");
     if (dw_direct(g, b)) {
         DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
@@ -2341,6 +2345,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
             case KAN_BASIS_POLY: KAN_DWD(KAN_BASIS_POLY); break;
             case KAN_BASIS_FOURIER: KAN_DWD(KAN_BASIS_FOURIER); break;
             case KAN_BASIS_RELU: KAN_DWD(KAN_BASIS_RELU); break;
+            case KAN_BASIS_GRAM: KAN_DWD(KAN_BASIS_GRAM); break;
             default: KAN_DWD(KAN_BASIS_CHEBY); break;
         }
 #undef KAN_DWD
@@ -2383,6 +2388,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_BD(KAN_BASIS_FOURIER);
     else if (b->kind == KAN_BASIS_RELU) KAN_BD(KAN_BASIS_RELU);
+    else if (b->kind == KAN_BASIS_GRAM) KAN_BD(KAN_BASIS_GRAM);
     else KAN_BD(KAN_BASIS_CHEBY);
 #undef KAN_BD2
 #undef KAN_BD
@@ -2394,7 +2400,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !dwp) return fail("null tensor pointer");
-    if (b->kind == KAN_BASIS_RELU && !b->chan_table) return fail("ReLU basis needs the per-channel phase table (chan_table)");
+    if ((b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) && !b->chan_table) return fail("ReLU / Gram bases need their device parameter table (chan_table)");
     if (dw_direct(g, b)) {
         DevGeom dgd = dev_geom(g); DevBasis dbd = dev_basis(b);
         dim3 grid(pl.bwd_weight_splits, ngroups(g));
@@ -2405,6 +2411,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
             case KAN_BASIS_POLY: KAN_DWW(KAN_BASIS_POLY); break;
             case KAN_BASIS_FOURIER: KAN_DWW(KAN_BASIS_FOURIER); break;
             case KAN_BASIS_RELU: KAN_DWW(KAN_BASIS_RELU); break;
+            case KAN_BASIS_GRAM: KAN_DWW(KAN_BASIS_GRAM); break;
             default: KAN_DWW(KAN_BASIS_CHEBY); break;
         }
 #undef KAN_DWW
@@ -2443,6 +2450,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     else if (b->kind == KAN_BASIS_POLY) KAN_BW_KIND(KAN_BASIS_POLY);
     else if (b->kind == KAN_BASIS_FOURIER) KAN_BW_KIND(KAN_BASIS_FOURIER);
     else if (b->kind == KAN_BASIS_RELU) KAN_BW_KIND(KAN_BASIS_RELU);
+    else if (b->kind == KAN_BASIS_GRAM) KAN_BW_KIND(KAN_BASIS_GRAM);
     else KAN_BW_KIND(KAN_BASIS_CHEBY);
 #undef KAN_BW_FAST
 #undef KAN_BW_KIND

@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .conv_layers import ChebyKANConv2DLayer, FastKANConv2DLayer, KANConv2DLayer
 from .relu_layers import ReLUKANConv2DLayer
+from .gram_layers import GRAMKANConv2DLayer
 from .poly_layers import (BersnsteinKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, LegendreKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
                           JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 
@@ -206,6 +207,18 @@ def relukan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, group
                               base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
 
 
+def gramkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, degree: int = 3, groups: int = 1, stride: _IntOrPair = 1,
+                 dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, dropout: float = 0.0,
+                 norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, l1_decay: float = 0.0,
+                 **norm_kwargs) -> GRAMKANConv2DLayer:
+    """layers/kan_conv.py:158-194 (no base_activation argument: the 2-D GRAM layer always runs SiLU)."""
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    _no_l1(l1_decay)
+    return GRAMKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
+                              padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer, **norm_kwargs)
+
+
 def laguerrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
                      dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
                      degree: int = 3, alpha: float = 1.0, base_activation: Optional[Callable[..., nn.Module]] = nn.GELU,
@@ -246,6 +259,7 @@ def taylorkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gro
 CONV_KAN_FACTORY = {
     "KAN": kan_conv,
     "FastKAN": fastkan_conv,
+    "GRAMKAN": gramkan_conv,
     "ChebyKAN": chebykan_conv,
     "LegendreKAN": legendrekan_conv,
     "BersnsteinKAN": bersnsteinkan_conv,

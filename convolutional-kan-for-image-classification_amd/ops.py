@@ -338,8 +338,9 @@ class _KanConvPhased(torch.autograd.Function):
         weights = [_require(w, "weight") for w in weights]
         w_base, w_basis = _split_weights(spec, weights)
         G = spec.groups
-        if tuple(phases.shape) != (x.shape[1] // G, 2, spec.n_basis):
-            raise L.KanConvError(f"phase table {tuple(phases.shape)} != (channels per group, 2, n_basis) = {(x.shape[1] // G, 2, spec.n_basis)}")
+        want = (x.shape[1] // G, 2, spec.n_basis) if spec.kind == L.BASIS_RELU else (spec.n_basis,)
+        if tuple(phases.shape) != want:
+            raise L.KanConvError(f"parameter table {tuple(phases.shape)} != {want} for basis kind {spec.kind}")
         with torch.cuda.device(x.device):
             z, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, bool(ctx.needs_input_grad[1]), phases)
             z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
@@ -361,13 +362,18 @@ class _KanConvPhased(torch.autograd.Function):
         with torch.cuda.device(x.device):
             dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w, phases)
             if need_p:
-                Cg, n = phases.shape[0], spec.n_basis
+                Cg, n = x.shape[1] // G, spec.n_basis
                 W = torch.stack(list(w_basis)).view(G, -1, Cg, n, spec.kernel[0] * spec.kernel[1])
-                parts = []
-                for mode in (1, 2):
+
+                def factor(mode):                               # wgrad of the parameter-derivative planes, times the weights
                     _, _, _, dwm = _conv_backward(spec, x, None, packed, dz, False, False, True, phases, mode)
-                    parts.append((W * torch.stack(list(dwm)).view_as(W)).sum(dim=(0, 1, 4)))
-                dph = torch.stack(parts, dim=1)
+                    return W * torch.stack(list(dwm)).view_as(W)
+                if spec.kind == L.BASIS_RELU:                  # per-channel phases [Cg, 2, n]
+                    dph = torch.stack([factor(mode).sum(dim=(0, 1, 4)) for mode in (1, 2)], dim=1)
+                else:                                          # Gram: layer-global coefficients c_2..c_degree (entries 0, 1 unused)
+                    dph = torch.zeros_like(phases)
+                    for mode in range(1, n - 1):
+                        dph[mode + 1] = factor(mode).sum()
         return (None, dx if need_x else None, dph) + _flat_grads(spec, dwb, dws)
 
 
@@ -499,7 +505,8 @@ def kan_conv(spec: ConvSpec, x: torch.Tensor, xn: Optional[torch.Tensor], w_base
 
 def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_base: Sequence[torch.Tensor],
                     w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
-    """Conv stage of the ReLU-KAN basis; `phases` = [channels per group, 2, n_basis] (low, high), differentiable."""
+    """Conv stage of a basis with trainable parameters held in device memory, differentiable in them: ReLU-KAN
+    (`phases` = [channels per group, 2, n_basis]: low, high) or Gram (`phases` = [n_basis] recurrence coefficients c_k)."""
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     return _KanConvPhased.apply(spec, x, phases, *ws)
 

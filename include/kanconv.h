@@ -33,7 +33,7 @@ extern "C" {
 #define KAN_MAX_TABLE  32   /* knots (B-spline) or centres (RBF) */
 
 /* basis families */
-enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3, KAN_BASIS_FOURIER = 4, KAN_BASIS_RELU = 5 };
+enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3, KAN_BASIS_FOURIER = 4, KAN_BASIS_RELU = 5, KAN_BASIS_GRAM = 6 };
 /* base-branch activations; KAN_ACT_NONE = layer has no base branch (ChebyKAN) */
 enum { KAN_ACT_NONE = -1, KAN_ACT_IDENTITY = 0, KAN_ACT_GELU = 1, KAN_ACT_SILU = 2, KAN_ACT_RELU = 3,
        KAN_ACT_TANH = 4, KAN_ACT_SIGMOID = 5, KAN_ACT_GELU_TANH = 6 };
@@ -70,13 +70,18 @@ typedef struct KanGeom {
  *              planes hold: 0 the basis; 1 / 2 its derivative w.r.t. phase_low / phase_high (base plane zero), so
  *              that kan_conv_bwd_weight yields the factor of the phase gradient,
  *              d phase[c][j] = sum_{o,tap} W[o][c*n+j][tap] * dW_mode[o][c*n+j][tap].
+ *   Gram     : n_basis = degree + 1 planes act(P_k(tanh x)), P_0 = 1, P_1 = t, P_k = t P_{k-1} - c_k P_{k-2}, the planes
+ *              passed through the layer's activation `act` (layers/gram_kan_layers.py:150-182).  The c_k derive from the
+ *              trainable `beta_weights`, so they are read from device memory: chan_table[k] = c_k, k = 2..degree (entries 0, 1
+ *              unused; one row for the whole layer).  `order` = 0: the basis; m >= 1: its derivative w.r.t. c_{m+1}
+ *              (base plane zero), for the coefficient gradient through kan_conv_bwd_weight as for ReLU.
  * `act` is the base-branch activation (KAN_ACT_NONE: no base branch, no base weight).
  * Planes per channel P = n_basis + (act != KAN_ACT_NONE); P <= KAN_MAX_PLANES. */
 typedef struct KanBasis {
     int kind, n_basis, order, act;
     float p0, p1;
     float table[KAN_MAX_TABLE];
-    const float* chan_table;      /* device pointer, KAN_BASIS_RELU only: [C][2][n_basis] floats; NULL otherwise */
+    const float* chan_table;      /* device pointer: KAN_BASIS_RELU [C][2][n_basis] floats, KAN_BASIS_GRAM [n_basis] floats; else NULL */
 } KanBasis;
 
 /* Launch plan for one geometry: split counts and workspace sizes (bytes). */

@@ -286,6 +286,37 @@ def relukan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_relukan: Sequence[Tens
     return _per_group(x, groups, one)
 
 
+def gram_basis(t: Tensor, beta_weights: Tensor, degree: int) -> Tensor:
+    """[B, C, degree+1, H, W]: Gram polynomials of t, p_i = t p_{i-1} - beta(i-1, i) p_{i-2},
+    beta(n, m) = (m+n)(m-n) n^2 / (m^2 / (4 n^2 - 1)) * beta_weights[n]  (gram_kan_layers.py:150-170)."""
+    p0, p1 = torch.ones_like(t), t
+    out = [p0, p1]
+    for i in range(2, degree + 1):
+        n, m = i - 1, i
+        beta = (((m + n) * (m - n) * n ** 2) / (m ** 2 / (4.0 * n ** 2 - 1.0))) * beta_weights[n]
+        p2 = t * p1 - beta * p0
+        out.append(p2)
+        p0, p1 = p1, p2
+    return torch.stack(out[:degree + 1], dim=2)
+
+
+def gramkan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, beta_weights: Tensor, *, degree: int,
+                   act: Optional[Callable[[Tensor], Tensor]], stride=1, padding=0, dilation=1, groups: int = 1,
+                   norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
+    """act(norm(conv(act(x), W_b) + conv(act(P(tanh x)), poly_weights[g]))), planes concatenated plane-major k*C + c
+    (gram_kan_layers.py:172-189)."""
+    f = (lambda v: v) if act is None else act
+
+    def one(xg, g):
+        planes = f(gram_basis(torch.tanh(xg), beta_weights, degree)).transpose(1, 2).flatten(1, 2)       # [B, n*C, H, W]
+        z = _conv(f(xg), w_base[g], stride, padding, dilation) + _conv(planes, poly_weights[g], stride, padding, dilation)
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        return f(n)
+    return _per_group(x, groups, one)
+
+
 def legendrekan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tensor, *, degree: int, stride=1, padding=0, dilation=1,
                        groups: int = 1, norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None,
                        pre_norm_out: Optional[list] = None) -> Tensor:

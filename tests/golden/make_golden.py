@@ -165,9 +165,25 @@ RELU_CASES = [
 ]
 
 
+# ---- GRAM-KAN (gram_kan_layers.py): trainable layer-global beta_weights, set far from their ~1e-3 init so that they matter
+GRAM_CASES = [
+    C("gram", "tiny", 2, 3, 4, 8, 8, degree=3),
+    C("gram", "deg5g2", 2, 4, 6, 7, 5, groups=2, degree=5, xs=1.5),
+    C("gram", "s2_affine", 3, 4, 6, 9, 9, s=2, degree=4, norm_kwargs={"affine": True}),
+    C("gram", "deg1_k5", 2, 3, 5, 9, 9, k=5, p=2, degree=1),
+    C("gram", "wide_deg6", 3, 20, 40, 6, 6, degree=6, xs=2.0),
+    C("gram", "batchnorm_d2", 3, 4, 8, 8, 8, degree=2, d=2, p=2, norm="bn"),
+]
+
+
 def build_ref(c):
     kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
     one_d = c.get("ndim", 2) == 1
+    if c["kind"] == "gram":
+        kw.update(c.get("norm_kwargs", {}))
+        if "norm" in c:
+            kw["norm_layer"] = NORMS[c["norm"]]
+        return REF_LAYERS.GRAMKANConv2DLayer(c["C"], c["O"], degree=c["degree"], **kw)
     if c["kind"] == "relu":
         kw.update(c.get("norm_kwargs", {}))
         kw.update(c.get("extra", {}))
@@ -247,6 +263,9 @@ def oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
         return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)],
                                 [sd[f"spline_conv.{g}.weight"] for g in range(G)],
                                 centres=centres, denom=denom, act=act, norm=norms, **geo)
+    if c["kind"] == "gram":
+        return O.gramkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], sd["beta_weights"],
+                                degree=layer.degree, act=ACT_FN["silu"], norm=norms, pre_norm_out=pre, **geo)
     if c["kind"] == "relu":
         return O.relukan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"relukan_conv.{g}.weight"] for g in range(G)],
                                 sd["phase_low"], sd["phase_high"], g=layer.g, k=layer.k, act=ACT_FN[c.get("act", "silu")], norm=norms,
@@ -280,6 +299,8 @@ def run_case(idx, c):
         for j, (n, p) in enumerate(layer.named_parameters()):
             if "prelus" in n:
                 p.fill_(0.25 if j % 2 else 0.1)
+            elif n == "beta_weights":                           # GRAM-KAN: O(0.1) recurrence coefficients instead of the ~1e-3 init
+                det_fill(p, idx * 31 + j, 0.25)
             elif n.startswith("phase"):                         # ReLU-KAN phases: channels and planes drift apart as in training
                 d = torch.empty(p.shape); det_fill(d, idx * 31 + j, 0.07)      # (the reference's Parameter is an expand() view whose
                 p.data = p.data.clone() + d                                    #  channels alias one row: give it its own memory)
@@ -300,7 +321,7 @@ def run_case(idx, c):
 
     pre_ref = []
     hooks = []
-    if c["kind"] in ("bspline", "cheby", "relu") or c["kind"] in POLY_FAMILIES:
+    if c["kind"] in ("bspline", "cheby", "relu", "gram") or c["kind"] in POLY_FAMILIES:
         for g in range(c["groups"]):
             hooks.append(layer.layer_norm[g].register_forward_pre_hook(lambda m, a: pre_ref.append(a[0].detach().clone())))
     y = layer(x)
@@ -466,6 +487,12 @@ def relu_cases():
         print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 
 
+def gram_cases():
+    for i, c in enumerate(GRAM_CASES):
+        worst, sz = run_case(7100 + i, c)
+        print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 def mlp_cases():
     for i, c in enumerate(MLP_CASES):
         worst, sz = run_mlp_case(i, c)
@@ -534,6 +561,8 @@ def main():
         return cases_1d()
     if "--relu-only" in sys.argv:
         return relu_cases()
+    if "--gram-only" in sys.argv:
+        return gram_cases()
     total = 0
     for i, c in enumerate(CASES):
         worst, sz = run_case(i, c)
@@ -544,6 +573,7 @@ def main():
     poly_cases()
     cases_1d()
     relu_cases()
+    gram_cases()
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)

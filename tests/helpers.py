@@ -29,6 +29,9 @@ def layer_kwargs(c):
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
         return kw
+    if c["kind"] == "gram":
+        kw["degree"] = c["degree"]
+        return kw
     if c["kind"] in POLY:
         kw.update(c.get("extra", {}))
         kw["grid_size" if c["kind"] == "fourier" else "degree"] = c["degree"]
@@ -52,6 +55,8 @@ def layer_kwargs(c):
 
 def build_layer(c):
     import convkan_amd as K
+    if c["kind"] == "gram":
+        return K.GRAMKANConv2DLayer(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] == "relu":
         return (K.ReLUKANConv1DLayer if c.get("ndim", 2) == 1 else K.ReLUKANConv2DLayer)(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] in POLY:
@@ -96,6 +101,9 @@ def _oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
         centres, denom = O.rbf_grid(layer.grid_size, layer.grid_range)
         return O.fastkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"spline_conv.{g}.weight"] for g in range(G)],
                                 centres=centres.to(x.device), denom=denom, act=ACT_FN[c.get("act", "silu")], norm=norms, **geo)
+    if c["kind"] == "gram":
+        return O.gramkan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], sd["poly_weights"], sd["beta_weights"],
+                                degree=layer.degree, act=ACT_FN["silu"], norm=norms, pre_norm_out=pre, **geo)
     if c["kind"] == "relu":
         return O.relukan_conv2d(x, [sd[f"base_conv.{g}.weight"] for g in range(G)], [sd[f"relukan_conv.{g}.weight"] for g in range(G)],
                                 sd["phase_low"], sd["phase_high"], g=layer.g, k=layer.k, act=ACT_FN[c.get("act", "silu")], norm=norms,

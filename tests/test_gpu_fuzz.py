@@ -122,13 +122,13 @@ def test_random_geometry_vs_oracle(seed, gpu_lib):
 ALL_FAMILIES = {"KAN": "bspline", "FastKAN": "rbf", "ChebyKAN": "cheby", "BesselKAN": "bessel", "FibonacciKAN": "fibonacci",
                 "GegenbauerKAN": "gegenbauer", "HermiteKAN": "hermite", "JacobiKAN": "jacobi", "LaguerreKAN": "laguerre",
                 "LucasKAN": "lucas", "TaylorKAN": "taylor", "FourierKAN": "fourier", "LegendreKAN": "legendre",
-                "BersnsteinKAN": "bersnstein", "ReLUKAN": "relu"}
+                "BersnsteinKAN": "bersnstein", "ReLUKAN": "relu", "GRAMKAN": "gram"}
 EXTRA = {"gegenbauer": {"alpha_param": 0.0}, "laguerre": {"alpha": 1.0}, "jacobi": {"a": 1.0, "b": 1.0}}
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KAN_FUZZ_FAM_N", "42"))))
 def test_random_family_vs_oracle(seed, gpu_lib):
-    """Every registered conv-KAN family (15 factory keys) on 3x3 'same' layers over the plane sizes and widths of the model zoo (incl. the
+    """Every registered conv-KAN family (16 factory keys) on 3x3 'same' layers over the plane sizes and widths of the model zoo (incl. the
     halo / 256-output-tile / position-major paths), affine or plain InstanceNorm."""
     r = random.Random(5000 + seed)
     fam = list(ALL_FAMILIES)[seed % len(ALL_FAMILIES)]
@@ -147,6 +147,9 @@ def test_random_family_vs_oracle(seed, gpu_lib):
     if fam == "ReLUKAN":                                          # phases drift apart per channel and plane, as after training
         with torch.no_grad():
             layer.phase_low.add_(0.06 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.06 * torch.randn_like(layer.phase_high))
+    if fam == "GRAMKAN":                                          # recurrence coefficients away from their ~1e-3 init
+        with torch.no_grad():
+            layer.beta_weights.normal_(0.0, 0.2)
     if affine:
         with torch.no_grad():
             for m in layer.layer_norm:

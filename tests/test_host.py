@@ -171,7 +171,13 @@ def test_polynomial_family_surface():
 def test_factory_signatures_and_same_padding():
     F = K.CONV_KAN_FACTORY
     poly = {"BesselKAN", "FibonacciKAN", "GegenbauerKAN", "HermiteKAN", "JacobiKAN", "LaguerreKAN", "LucasKAN", "TaylorKAN"}
-    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "ReLUKAN", "conv"} | poly
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "ReLUKAN", "GRAMKAN", "conv"} | poly
+    gr = F["GRAMKAN"](4, 6, 3, groups=2, dilation=2)            # kan_conv.py:158-194; gram_kan_layers.py:85-148
+    assert (gr.padding, gr.dilation, gr.degree) == (2, 2, 3) and isinstance(gr.base_activation, nn.SiLU)
+    assert list(gr.state_dict()) == ["poly_weights", "beta_weights", "base_conv.0.weight", "base_conv.1.weight"]
+    assert gr.poly_weights.shape == (2, 3, 2 * 4, 3, 3) and gr.beta_weights.shape == (4,) and gr.conv_spec().kind == L.BASIS_GRAM
+    assert list(inspect.signature(F["GRAMKAN"]).parameters)[3] == "degree" and "base_activation" not in inspect.signature(F["GRAMKAN"]).parameters
+    assert abs(float(gr._beta_factor[2]) - 3 * 1 * 1 / (4 / 3.0)) < 1e-6 and float(gr._beta_factor[:2].abs().sum()) == 0
     rl = F["ReLUKAN"](4, 6, 3, groups=2, dilation=2)             # kan_conv.py:652-690; relu_kan_layers.py:41-116
     assert (rl.padding, rl.dilation, rl.g, rl.k, rl.r, rl.train_ab) == (2, 1, 5, 3, 6.25, True) and isinstance(rl.base_activation, nn.GELU)
     assert list(rl.state_dict()) == ["phase_low", "phase_high", "base_conv.0.weight", "base_conv.1.weight", "relukan_conv.0.weight",

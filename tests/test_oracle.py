@@ -31,6 +31,8 @@ class _Params(nn.Module):
         if "sd.poly_weights" in d:                                # JacobiKAN: one [G, O/G, C/G*(deg+1), k, k] parameter
             self.poly_weights = nn.Parameter(torch.from_numpy(d["sd.poly_weights"]))
             self.a, self.b = c.get("extra", {}).get("a"), c.get("extra", {}).get("b")
+        if "sd.beta_weights" in d:                                # GRAM-KAN: layer-global recurrence parameters
+            self.beta_weights = nn.Parameter(torch.from_numpy(d["sd.beta_weights"]))
         if "sd.phase_low" in d:                                   # ReLU-KAN: per-channel phases, g / k from the case
             self.phase_low, self.phase_high = (nn.Parameter(torch.from_numpy(d["sd.phase_" + w])) for w in ("low", "high"))
             self.g, self.k = c.get("extra", {}).get("g", 5), c.get("extra", {}).get("k", 3)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "kan_slab_reduce": (_I, [_P, _I, _LL, _P, _I, _I, _I, _LL, _P]),
     "kan_instnorm_prelu_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _F, _I, _P]),
     "kan_instnorm_prelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _I, _P]),
+    "kan_instnorm_prelu_pool_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _F, _I, _P]),
+    "kan_instnorm_prelu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _I, _P]),
     "kan_adamw_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _F, _P]),
     "kan_adamw_step_segments": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _D, _D, _I, _F, _P]),
 }

@@ -1579,7 +1579,8 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
                                                       float* __restrict__ z_out, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ prelu_a,
                                                       float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                      int n_planes, int Cn, int HW, long long bstride, float eps, int prelu_span) {
+                                                      int n_planes, int Cn, int HW, long long bstride, float eps, int prelu_span,
+                                                      unsigned char* __restrict__ pidx, int W) {
     const int tid = threadIdx.x, sub = tid % G;
     const int plane = blockIdx.x * (256 / G) + tid / G;
     const bool act = plane < n_planes;
@@ -1611,9 +1612,28 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const bool has_p = prelu_a != nullptr;
     const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;     // one slope per `prelu_span` channels (0: one for all)
-    for (int i = sub; i < HW; i += G) {
-        float n = (z_out[base + i] - mu) * rs * ga + be;
-        y[base + i] = (has_p && !(n > 0.f)) ? a * n : n;
+    if (pidx) {
+        // fused MaxPool2d(2, 2) (the VGG pattern: kan_vgg.py:97-101 puts one right after the layer): y and pidx are the dense
+        // pooled [B][Cn][H/2][W/2] tensors, pidx the position 2*dh + dw of the maximum -- first maximum in scan order, NaN wins,
+        // as torch's max_pool2d picks it.  The full-size activation is never written.
+        const int W2 = W >> 1, Q = HW >> 2;
+        const size_t pbase = (size_t)plane * Q;
+        for (int q = sub; q < Q; q += G) {
+            const int h2 = q / W2, w2 = q - h2 * W2, i0 = 2 * h2 * W + 2 * w2;
+            float best = 0.f; int arg = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float n = (z_out[base + i0 + (k >> 1) * W + (k & 1)] - mu) * rs * ga + be;
+                const float v = (has_p && !(n > 0.f)) ? a * n : n;
+                if (k == 0 || v > best || v != v) { best = v; arg = k; }
+            }
+            y[pbase + q] = best; pidx[pbase + q] = (unsigned char)arg;
+        }
+    } else {
+        for (int i = sub; i < HW; i += G) {
+            float n = (z_out[base + i] - mu) * rs * ga + be;
+            y[base + i] = (has_p && !(n > 0.f)) ? a * n : n;
+        }
     }
     if (sub == 0) { mean_o[plane] = mu; rstd_o[plane] = rs; }
 }
@@ -1624,7 +1644,8 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ prelu_a, float* __restrict__ dz,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dprelu,
-                                                      int n_planes, int Cn, int HW, long long bstride, int prelu_span) {
+                                                      int n_planes, int Cn, int HW, long long bstride, int prelu_span,
+                                                      const unsigned char* __restrict__ pidx, int W) {
     constexpr int EPL = 16;                         // elements per lane held in registers between the two passes
     __shared__ float s_da[256 / G];
     const int tid = threadIdx.x, sub = tid % G;
@@ -1643,6 +1664,14 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;
     float rn[EPL], rd[EPL];                         // normalised value, d loss / d normalised value
     float s1 = 0.f, s2 = 0.f, sa = 0.f, sg = 0.f, sb = 0.f;
+    // upstream gradient of element i: plain, or through the fused MaxPool2d(2, 2) -- dy is then the dense pooled gradient and
+    // only the element the forward marked in pidx receives it
+    auto gy = [&](int i) -> float {
+        if (!pidx) return dy[base + i];
+        const int h = i / W, w = i - h * W;
+        const size_t pq = (size_t)plane * (HW >> 2) + (size_t)((h >> 1) * (W >> 1) + (w >> 1));
+        return pidx[pq] == (unsigned char)((h & 1) * 2 + (w & 1)) ? dy[pq] : 0.f;
+    };
     auto visit = [&](float zv, float g, float& nh, float& dnh) {
         nh = (zv - mu) * rs;
         const float n = nh * ga + be;
@@ -1658,10 +1687,10 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
         for (int e = 0; e < EPL; ++e) {
             const int i = sub + e * G;
             rn[e] = 0.f; rd[e] = 0.f;
-            if (act && i < HW) visit(z[base + i], dy[base + i], rn[e], rd[e]);
+            if (act && i < HW) visit(z[base + i], gy(i), rn[e], rd[e]);
         }
     } else if (act) {
-        for (int i = sub; i < HW; i += G) { float nh, dnh; visit(z[base + i], dy[base + i], nh, dnh); }
+        for (int i = sub; i < HW; i += G) { float nh, dnh; visit(z[base + i], gy(i), nh, dnh); }
     }
     s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
     sa = group_sum<G>(sa); sg = group_sum<G>(sg); sb = group_sum<G>(sb);
@@ -1676,7 +1705,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
         for (int i = sub; i < HW; i += G) {
             float nh = (z[base + i] - mu) * rs;
             float n = nh * ga + be;
-            float g = dy[base + i];
+            float g = gy(i);
             bool neg = has_p && !(n > 0.f);
             float dnh = (neg ? a * g : g) * ga;
             dz[base + i] = rs * (dnh - m1 - nh * m2);
@@ -2052,21 +2081,22 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
 
 template <int G>
 void launch_in_fwd(hipStream_t st, int planes, const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma,
-                   const float* beta, const float* a, float* y, float* mean, float* rstd, int Cn, int HW, long long bs, float eps, int span) {
+                   const float* beta, const float* a, float* y, float* mean, float* rstd, int Cn, int HW, long long bs, float eps, int span,
+                   unsigned char* pidx = nullptr, int W = 0) {
     int ppb = 256 / G;
     hipLaunchKernelGGL((k_in_prelu_fwd<G>), dim3(ceil_div(planes, ppb)), dim3(256), 0, st, z, n_slabs, slab_elems, z_out, gamma, beta, a, y,
-                       mean, rstd, planes, Cn, HW, bs, eps, span);
+                       mean, rstd, planes, Cn, HW, bs, eps, span, pidx, W);
 }
 template <int G>
 void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW, long long bs,
-                   int span) {
+                   int span, const unsigned char* pidx = nullptr, int W = 0) {
     int ppb = 256 / G;
     int blocks = ceil_div(planes, ppb);
     const int cap = (long long)planes * HW < (4ll << 20) ? 512 : 2048;       // small tensors: fewer same-address atomics on dprelu
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
-                       dbeta, dprelu, planes, Cn, HW, bs, span);
+                       dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W);
 }
 // Lanes per (b, channel) plane.
 int group_lanes(int HW) {          // (more elements per lane was measured: no gain)
@@ -2467,36 +2497,65 @@ int kan_slab_reduce(const float* slabs, int n_slabs, long long slab_elems, float
     return launch_ok("slab_reduce");
 }
 
-int kan_instnorm_prelu_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
-                           const float* prelu_a, float* y, float* mean, float* rstd, int B, int Cn, int HW, long long bstride, float eps,
-                           int prelu_span, void* stream) {
+static int instnorm_fwd_any(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
+                            const float* prelu_a, float* y, float* mean, float* rstd, int B, int Cn, int HW, long long bstride, float eps,
+                            int prelu_span, unsigned char* pidx, int W, void* stream) {
     if (!z || !z_out || !y || !mean || !rstd || n_slabs < 1 || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_fwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
     switch (group_lanes(HW)) {
-        case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
-        case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
-        case 16: launch_in_fwd<16>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
-        case 32: launch_in_fwd<32>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
-        default: launch_in_fwd<64>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span); break;
+        case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
+        case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
+        case 16: launch_in_fwd<16>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
+        case 32: launch_in_fwd<32>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
+        default: launch_in_fwd<64>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
     }
     return launch_ok("instnorm_fwd");
+}
+
+int kan_instnorm_prelu_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
+                           const float* prelu_a, float* y, float* mean, float* rstd, int B, int Cn, int HW, long long bstride, float eps,
+                           int prelu_span, void* stream) {
+    return instnorm_fwd_any(z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, B, Cn, HW, bstride, eps, prelu_span, nullptr, 0,
+                            stream);
+}
+
+int kan_instnorm_prelu_pool_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
+                                const float* prelu_a, float* y_pooled, unsigned char* pool_idx, float* mean, float* rstd, int B, int Cn,
+                                int H, int W, long long bstride, float eps, int prelu_span, void* stream) {
+    if (!pool_idx || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("fused 2x2 max-pool needs even H and W and an index buffer");
+    return instnorm_fwd_any(z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y_pooled, mean, rstd, B, Cn, H * W, bstride, eps, prelu_span,
+                            pool_idx, W, stream);
+}
+
+static int instnorm_bwd_any(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                            const float* prelu_a, float* dz, float* dgamma, float* dbeta, float* dprelu, int B, int Cn, int HW,
+                            long long bstride, int prelu_span, const unsigned char* pidx, int W, void* stream) {
+    if (!dy || !z || !mean || !rstd || !dz || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_bwd arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int planes = B * Cn;
+    switch (HW == 64 ? 16 : group_lanes(HW)) {      // 8x8 planes: 4 elements per lane (measured 52 -> 37 us on 256x256x8x8)
+        case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
+        case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
+        case 16: launch_in_bwd<16>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
+        case 32: launch_in_bwd<32>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
+        default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
+    }
+    return launch_ok("instnorm_bwd");
 }
 
 int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                            const float* prelu_a, float* dz, float* dgamma, float* dbeta, float* dprelu, int B, int Cn, int HW,
                            long long bstride, int prelu_span, void* stream) {
-    if (!dy || !z || !mean || !rstd || !dz || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_bwd arguments");
-    hipStream_t st = (hipStream_t)stream;
-    int planes = B * Cn;
-    switch (HW == 64 ? 16 : group_lanes(HW)) {      // 8x8 planes: 4 elements per lane (measured 52 -> 37 us on 256x256x8x8)
-        case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
-        case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
-        case 16: launch_in_bwd<16>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
-        case 32: launch_in_bwd<32>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
-        default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span); break;
-    }
-    return launch_ok("instnorm_bwd");
+    return instnorm_bwd_any(dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, B, Cn, HW, bstride, prelu_span, nullptr, 0, stream);
+}
+
+int kan_instnorm_prelu_pool_bwd(const float* dy_pooled, const unsigned char* pool_idx, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, const float* prelu_a, float* dz, float* dgamma, float* dbeta,
+                                float* dprelu, int B, int Cn, int H, int W, long long bstride, int prelu_span, void* stream) {
+    if (!pool_idx || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("fused 2x2 max-pool needs even H and W and the forward's index buffer");
+    return instnorm_bwd_any(dy_pooled, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, B, Cn, H * W, bstride, prelu_span,
+                            pool_idx, W, stream);
 }
 
 int kan_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,

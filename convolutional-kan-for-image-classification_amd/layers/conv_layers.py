@@ -164,13 +164,19 @@ class KANConvNDLayer(_HipLayer):
         return self._spec(kind=L.BASIS_BSPLINE, n_basis=self.grid_size + self.spline_order, order=self.spline_order,
                           act=self._act_code, p0=0.0, p1=0.0, table=tuple(float(v) for v in self.grid.tolist()))
 
-    def forward(self, x):
+    def forward(self, x, pool: bool = False):
+        """`pool=True` (not part of the reference signature; used by models/kan_vgg.py for a layer that is followed by
+        MaxPool2d(2, 2)) returns max_pool2d(layer(x), 2, 2) with the pooling done inside the InstanceNorm+PReLU kernels."""
         spec = self.conv_spec()
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.spline_conv)
         prelus = [m.weight for m in self.prelus]
         if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
+            if pool and self.ndim == 2 and self.dropout is None:
+                ho, wo = spec.out_hw(x.shape[2], x.shape[3])
+                if ho % 2 == 0 and wo % 2 == 0:
+                    return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
             # other norm classes (e.g. BatchNorm2d): HIP conv stage, then the caller's own norm module
@@ -179,7 +185,7 @@ class KANConvNDLayer(_HipLayer):
             y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
             y = self.dropout(y)
-        return y
+        return F.max_pool2d(y, 2, 2) if pool else y
 
 
 class KANConv1DLayer(KANConvNDLayer):

@@ -6,6 +6,7 @@ so a reference ``state_dict`` loads unchanged.  Adds the ``VGG11`` cfg that BASE
 kan_vgg.py:20-26).  Only plain heads ('Linear', 'VGG') are offered: KAN MLP heads are out of the
 accelerated path's first "next" row and are built on the same conv stage.
 """
+import os
 from functools import partial
 from inspect import signature
 from math import prod
@@ -14,6 +15,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 
+from ..layers.conv_layers import KANConvNDLayer
 from ..layers.kan_conv import CONV_KAN_FACTORY
 from ..layers.mlp_layers import MLP_KAN_FACTORY
 
@@ -76,6 +78,7 @@ class VGGKAN(nn.Module):
                 cin = cout
         self.features = nn.ModuleList(feats)
         self.avgpool = nn.AdaptiveAvgPool2d(expected_feature_shape)
+        self.fuse_pool = os.environ.get("KAN_FUSE_POOL", "1") != "0"      # plain attribute: set False for the unfused sequence
         kan_head = None
         if classifier_type in ("KAN", "HiddenKAN", "VGGKAN"):
             name = kan_classifier or "KAN"
@@ -92,13 +95,32 @@ class VGGKAN(nn.Module):
         self.name = f"VGGKAN_{head}_{kan_conv.upper()}_{arch}"
 
     def forward_features(self, x):
-        for layer in self.features:
-            x = layer(x)
+        """kan_vgg.py:142-146 `self.features(x)`, with one fusion: a B-spline KAN layer directly followed by the "M" entry
+        (MaxPool2d(2, 2)) runs the pooling inside its InstanceNorm+PReLU kernels, so the un-pooled activation and its
+        gradient never go through HBM.  Same values as the two modules in sequence (tests/test_gpu_models.py)."""
+        mods = list(self.features)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (self.fuse_pool and isinstance(m, KANConvNDLayer) and isinstance(nxt, nn.MaxPool2d) and _is_pool_2x2(nxt)):
+                x = m(x, pool=True)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
         return x
 
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         x = self.avgpool(self.forward_features(x))
         return self.classifier(torch.flatten(x, 1))
+
+
+def _is_pool_2x2(m: nn.MaxPool2d) -> bool:
+    two = lambda v: v == 2 or v == (2, 2)
+    zero = lambda v: v == 0 or v == (0, 0)
+    one = lambda v: v == 1 or v == (1, 1)
+    return two(m.kernel_size) and two(m.stride) and zero(m.padding) and one(m.dilation) and not m.ceil_mode and not m.return_indices
 
 
 def vggkan(input_channels: int, num_classes: int, conv_type: str = "kanconv", kan_conv: Optional[str] = "KAN",

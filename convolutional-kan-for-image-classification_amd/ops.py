@@ -385,11 +385,11 @@ def _cat(ts: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
 
 
 class _KanConvInPrelu(torch.autograd.Function):
-    """y = [PReLU](InstanceNorm(conv stage)).
-    args: spec, eps, use_affine, use_prelu, x, *[w_base_g], *[w_basis_g], *[gamma_g], *[beta_g], *[prelu_g]"""
+    """y = [MaxPool2d(2, 2)]([PReLU](InstanceNorm(conv stage))).
+    args: spec, eps, use_affine, use_prelu, pool, x, *[w_base_g], *[w_basis_g], *[gamma_g], *[beta_g], *[prelu_g]"""
 
     @staticmethod
-    def forward(ctx, spec: ConvSpec, eps: float, use_affine: bool, use_prelu: bool, x, *params):
+    def forward(ctx, spec: ConvSpec, eps: float, use_affine: bool, use_prelu: bool, pool: bool, x, *params):
         lib = L.load()
         x = _require(x, "x")
         params = [_require(p, "parameter") for p in params]
@@ -402,32 +402,46 @@ class _KanConvInPrelu(torch.autograd.Function):
         prelus = rest[2 * G * int(use_affine):] if use_prelu else [None] * G
         if use_prelu and any(p.numel() != 1 for p in prelus):
             raise L.KanConvError("only scalar-slope PReLU (nn.PReLU()) is supported, as in kan_layers.py:182")
-        need_dgrad = bool(ctx.needs_input_grad[4])
+        need_dgrad = bool(ctx.needs_input_grad[5])
         with torch.cuda.device(x.device):
             zs, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, need_dgrad, cache_ok=_CALL.no_grad)
             S, B, Ot, Ho, Wo = zs.shape
             Og, HW = Ot // G, Ho * Wo
-            y = torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
             mean = torch.empty(B * Ot, device=x.device, dtype=torch.float32)
             rstd = torch.empty_like(mean)
             # all groups in one launch: per-channel gamma/beta concatenated, one PReLU slope per Og channels
             gamma, beta, slope = _cat(gammas), _cat(betas), _cat(prelus)
-            L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(zs), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(y),
-                                               _ptr(mean), _ptr(rstd), B, Ot, HW, Ot * HW, eps, Og if G > 1 else 0, _stream(x)),
-                    "kan_instnorm_prelu_fwd")
+            pidx = None
+            if pool:                                     # MaxPool2d(2, 2) fused behind the PReLU: the full-size y is never written
+                if Ho % 2 or Wo % 2:
+                    raise L.KanConvError(f"fused 2x2 max-pool needs an even plane, got {Ho}x{Wo}")
+                y = torch.empty((B, Ot, Ho // 2, Wo // 2), device=x.device, dtype=torch.float32)
+                pidx = torch.empty((B, Ot, Ho // 2, Wo // 2), device=x.device, dtype=torch.uint8)
+                L.check(lib.kan_instnorm_prelu_pool_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(zs), _ptr(gamma), _ptr(beta), _ptr(slope),
+                                                        _ptr(y), C.c_void_p(pidx.data_ptr()), _ptr(mean), _ptr(rstd), B, Ot, Ho, Wo,
+                                                        Ot * HW, eps, Og if G > 1 else 0, _stream(x)), "kan_instnorm_prelu_pool_fwd")
+            else:
+                y = torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
+                L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(zs), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(y),
+                                                   _ptr(mean), _ptr(rstd), B, Ot, HW, Ot * HW, eps, Og if G > 1 else 0, _stream(x)),
+                        "kan_instnorm_prelu_fwd")
         z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
-        ctx.spec, ctx.flags = spec, (use_affine, use_prelu)
+        ctx.spec, ctx.flags = spec, (use_affine, use_prelu, pool)
         ctx.layout = (packed[0] is not None, packed[1] is not None)
-        ctx.save_for_backward(x, z, mean, rstd, *[t for t in packed if t is not None], *[t for t in (gamma, beta, slope) if t is not None])
+        ctx.save_for_backward(x, z, mean, rstd, *[t for t in packed if t is not None], *[t for t in (gamma, beta, slope) if t is not None],
+                              *([pidx] if pool else []))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = L.load()
         spec = ctx.spec
-        use_affine, use_prelu = ctx.flags
+        use_affine, use_prelu, pool = ctx.flags
         G = spec.groups
         saved = ctx.saved_tensors
+        pidx = saved[-1] if pool else None
+        if pool:
+            saved = saved[:-1]
         x, z, mean, rstd = saved[:4]
         nwd = int(ctx.layout[0]) + int(ctx.layout[1])
         packed = _unflatten(ctx.layout, list(saved[4:4 + nwd]))
@@ -435,26 +449,31 @@ class _KanConvInPrelu(torch.autograd.Function):
         gamma, beta = (rest[0], rest[1]) if use_affine else (None, None)
         slope = rest[2 * int(use_affine)] if use_prelu else None
         dy = dy.contiguous()
-        B, Ot, Ho, Wo = dy.shape
+        B, Ot, Ho, Wo = z.shape
         Og, HW = Ot // G, Ho * Wo
         with torch.cuda.device(x.device):
-            dz = torch.empty_like(dy)
+            dz = torch.empty_like(z)
             dgam = torch.zeros_like(gamma) if use_affine else None
             dbet = torch.zeros_like(beta) if use_affine else None
             dpre = torch.zeros_like(slope) if use_prelu else None
-            L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(dz),
-                                               _ptr(dgam), _ptr(dbet), _ptr(dpre), B, Ot, HW, Ot * HW, Og if G > 1 else 0, _stream(x)),
-                    "kan_instnorm_prelu_bwd")
+            if pool:
+                L.check(lib.kan_instnorm_prelu_pool_bwd(_ptr(dy), C.c_void_p(pidx.data_ptr()), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                                        _ptr(beta), _ptr(slope), _ptr(dz), _ptr(dgam), _ptr(dbet), _ptr(dpre), B, Ot, Ho, Wo,
+                                                        Ot * HW, Og if G > 1 else 0, _stream(x)), "kan_instnorm_prelu_pool_bwd")
+            else:
+                L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(dz),
+                                                   _ptr(dgam), _ptr(dbet), _ptr(dpre), B, Ot, HW, Ot * HW, Og if G > 1 else 0, _stream(x)),
+                        "kan_instnorm_prelu_bwd")
             nw = G * (2 if spec.has_base else 1)
-            need_x = ctx.needs_input_grad[4]
-            need_w = any(ctx.needs_input_grad[5:5 + nw])
+            need_x = ctx.needs_input_grad[5]
+            need_w = any(ctx.needs_input_grad[6:6 + nw])
             dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w)
         grads = _flat_grads(spec, dwb, dws)
         if use_affine:
             grads += tuple(dgam.view(G, Og).unbind(0)) + tuple(dbet.view(G, Og).unbind(0))
         if use_prelu:
             grads += tuple(dpre.view(G, 1).unbind(0))
-        return (None, None, None, None, dx if need_x else None) + grads
+        return (None, None, None, None, None, dx if need_x else None) + grads
 
 
 class _InstanceNorm(torch.autograd.Function):
@@ -513,13 +532,14 @@ def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_bas
 
 def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Tensor], w_basis: Sequence[torch.Tensor],
                       gammas: Optional[Sequence[torch.Tensor]], betas: Optional[Sequence[torch.Tensor]],
-                      prelus: Optional[Sequence[torch.Tensor]], eps: float = 1e-5) -> torch.Tensor:
+                      prelus: Optional[Sequence[torch.Tensor]], eps: float = 1e-5, pool: bool = False) -> torch.Tensor:
+    """`pool=True` additionally applies MaxPool2d(kernel 2, stride 2) inside the same kernels (even output planes only)."""
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     aff = gammas is not None
     extra = (list(gammas) + list(betas) if aff else []) + (list(prelus) if prelus is not None else [])
     _CALL.no_grad = _records_no_graph(x, *ws, *extra)
     try:
-        return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, x, *ws, *extra)
+        return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), x, *ws, *extra)
     finally:
         _CALL.no_grad = False
 

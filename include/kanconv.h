@@ -191,6 +191,19 @@ int kan_instnorm_prelu_bwd(const float* dy, const float* z, const float* mean, c
                            float* dz, float* dgamma, float* dbeta, float* dprelu,
                            int B, int Cn, int HW, long long bstride, int prelu_span, void* stream);
 
+/* The same pair with MaxPool2d(kernel 2, stride 2) fused behind the PReLU -- the VGG pattern (models/kan_vgg.py:97-101: a
+ * "M" entry right after the layer).  y_pooled / dy_pooled are dense [B][Cn][H/2][W/2]; pool_idx (same shape, bytes) holds the
+ * position 2*dh + dw of each window's maximum (first maximum in scan order, NaN wins: torch's max_pool2d rule) and carries
+ * the routing to the backward.  The full-size activation and its gradient never touch HBM.  H and W must be even. */
+int kan_instnorm_prelu_pool_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out,
+                                const float* gamma, const float* beta, const float* prelu_a,
+                                float* y_pooled, unsigned char* pool_idx, float* mean, float* rstd,
+                                int B, int Cn, int H, int W, long long bstride, float eps, int prelu_span, void* stream);
+int kan_instnorm_prelu_pool_bwd(const float* dy_pooled, const unsigned char* pool_idx, const float* z, const float* mean, const float* rstd,
+                                const float* gamma, const float* beta, const float* prelu_a,
+                                float* dz, float* dgamma, float* dbeta, float* dprelu,
+                                int B, int Cn, int H, int W, long long bstride, int prelu_span, void* stream);
+
 /* One AdamW step over a flat fp32 block of n elements, in place (p, m = exp_avg, v = exp_avg_sq; g is read only and
  * multiplied by grad_scale first).  Replaces the per-tensor update loop of torch.optim.AdamW as the reference builds it
  * (generic_train.py:24 `optim.AdamW(model.parameters(), lr, weight_decay)`, stepped once per batch: evaluations.py train()),

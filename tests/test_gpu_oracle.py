@@ -243,3 +243,51 @@ def test_vgg11_runs_and_is_batch_consistent_at_odd_batch_sizes(B, gpu_lib):
     with torch.no_grad():
         single = torch.cat([m(x[i:i + 1].detach()) for i in range(min(B, 3))])
     assert relerr(y[:single.shape[0]], single) <= 2e-3
+
+
+# ------------------------------------------------------------------------------------- fused MaxPool2d(2, 2)
+@pytest.mark.parametrize("case", [(3, 64, 32, 4, {}), (8, 128, 8, 6, {}), (16, 64, 4, 20, {}), (8, 12, 6, 3, dict(groups=2, affine=True)),
+                                  (4, 8, 2, 33, {}), (6, 16, 16, 2, dict(base_activation=None))],
+                         ids=lambda c: f"C{c[0]}-O{c[1]}-{c[2]}x{c[2]}")
+def test_fused_maxpool_equals_layer_then_maxpool(case, gpu_lib):
+    """layer(x, pool=True) -- the pooling inside the InstanceNorm+PReLU kernels -- against the same layer followed by torch's
+    MaxPool2d(2, 2) (kan_vgg.py:97-101): identical forward values, gradients equal to rounding."""
+    C, O, H, B, kw = case
+    torch.manual_seed(C + O + H)
+    layer = K.KANConv2DLayer(C, O, 3, padding=1, **kw).cuda()
+    with torch.no_grad():
+        layer.prelus[0].weight.fill_(0.3)
+    x = torch.randn(B, C, H, H, device="cuda")
+    go = torch.randn(B, O, H // 2, H // 2, device="cuda")
+    outs = []
+    for fused in (True, False):
+        layer.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi, pool=True) if fused else F.max_pool2d(layer(xi), 2, 2)
+        y.backward(go)
+        outs.append((y.detach(), xi.grad, {n: p.grad.clone() for n, p in layer.named_parameters()}))
+    (y1, dx1, g1), (y0, dx0, g0) = outs
+    assert torch.equal(y1, y0)
+    assert relerr(dx1, dx0) <= 2e-6
+    for n in g0:
+        assert relerr(g1[n], g0[n]) <= 2e-6, n
+    odd = K.KANConv2DLayer(3, 8, 3, padding=1).cuda()                           # odd planes fall back to the unfused sequence
+    xo = torch.randn(2, 3, 7, 7, device="cuda")
+    assert torch.equal(odd(xo, pool=True), F.max_pool2d(odd(xo), 2, 2))
+
+
+def test_vgg_fused_pool_matches_unfused_model(gpu_lib):
+    from convkan_amd.models import vggkan
+    torch.manual_seed(5)
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear", dropout_linear=0.0).cuda().train()
+    x, t = torch.randn(6, 3, 32, 32, device="cuda"), torch.randint(0, 10, (6,), device="cuda")
+    res = []
+    for fuse in (True, False):
+        m.fuse_pool = fuse
+        m.zero_grad(set_to_none=True)
+        logits = m(x)
+        F.cross_entropy(logits, t).backward()
+        res.append((logits.detach(), [p.grad.clone() for p in m.parameters()]))
+    assert relerr(res[0][0], res[1][0]) <= 1e-6
+    for a, b in zip(res[0][1], res[1][1]):
+        assert relerr(a, b) <= 1e-5

@@ -159,7 +159,10 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // src_kind 0: base weights [O][C][T] -> plane 0;   src_kind 1: basis weights [O][C*nb][T] -> plane hb + q.
 // A 32x32 tile goes through LDS so that both the read (along the source's contiguous (channel,tap) axis) and the
 // write (along o) coalesce.
-struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair; };
+// divT / divNb / divIPC / divP: magic numbers for the per-element index divisions below.  With plain `/` the three layout
+// kernels spent ~100 VALU instructions per element on integer division and were ALU-bound, not HBM-bound (0.81 ms of a
+// 17.4 ms KAN-VGG11 step for 1 GB of traffic).
+struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair; FastDiv divT, divNb, divIPC, divP; };
 
 // Row of (tap, channel c, plane p) in the forward layout.  pair == 0: tap-major items as described above.  pair == 1 (the
 // halo forward kernel, P = 9, C even): a step of KC = 18 rows is one tap of a channel PAIR, row 2p + (c & 1), steps
@@ -168,12 +171,12 @@ struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair; };
 __device__ __forceinline__ int wp_row(const PackGeo& q, int tap, int c, int p) {
     if (q.pair) return ((c >> 1) * q.T + tap) * q.KC + 2 * p + (c & 1);
     const int item = tap * q.C + c;                   // tap-major: all channels of a tap are contiguous in the depth axis
-    const int chunk = item / q.IPC;
+    const int chunk = fastdiv(item, q.divIPC);
     return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
 }
 __device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
-    int cq = j / q.T, tap = j - cq * q.T;
-    int c = src_kind == 0 ? cq : cq / q.nb;
+    int cq = fastdiv(j, q.divT), tap = j - cq * q.T;
+    int c = src_kind == 0 ? cq : fastdiv(cq, q.divNb);
     int p = src_kind == 0 ? 0 : q.hb + (cq - c * q.nb);
     return wp_row(q, tap, c, p);
 }
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
         int col = col0 + ty + 8 * i, o = o0 + tx;
         float v = 0.f;
         if (col < ncol) {
-            int hf = col >> 6, w = col & 63, cl = w / q.P, p = w - cl * q.P, c = hf * CH + cl;
+            int hf = col >> 6, w = col & 63, cl = fastdiv(w, q.divP), p = w - cl * q.P, c = hf * CH + cl;
             if (cl < CH && c < q.C && o < q.O) {
                 v = wp[(size_t)wp_row(q, tap, c, p) * q.Opad + o];
             }
@@ -1580,7 +1583,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
                                                       const float* __restrict__ beta, const float* __restrict__ prelu_a,
                                                       float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                       int n_planes, int Cn, int HW, long long bstride, float eps, int prelu_span,
-                                                      unsigned char* __restrict__ pidx, int W) {
+                                                      unsigned char* __restrict__ pidx, int W, FastDiv divW) {
     const int tid = threadIdx.x, sub = tid % G;
     const int plane = blockIdx.x * (256 / G) + tid / G;
     const bool act = plane < n_planes;
@@ -1619,7 +1622,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ 
         const int W2 = W >> 1, Q = HW >> 2;
         const size_t pbase = (size_t)plane * Q;
         for (int q = sub; q < Q; q += G) {
-            const int h2 = q / W2, w2 = q - h2 * W2, i0 = 2 * h2 * W + 2 * w2;
+            const int h2 = fastdiv(q, divW), w2 = q - h2 * W2, i0 = 2 * h2 * W + 2 * w2;      // divW: by W / 2 here
             float best = 0.f; int arg = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
                                                       const float* __restrict__ prelu_a, float* __restrict__ dz,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dprelu,
                                                       int n_planes, int Cn, int HW, long long bstride, int prelu_span,
-                                                      const unsigned char* __restrict__ pidx, int W) {
+                                                      const unsigned char* __restrict__ pidx, int W, FastDiv divW) {
     constexpr int EPL = 16;                         // elements per lane held in registers between the two passes
     __shared__ float s_da[256 / G];
     const int tid = threadIdx.x, sub = tid % G;
@@ -1668,7 +1671,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     // only the element the forward marked in pidx receives it
     auto gy = [&](int i) -> float {
         if (!pidx) return dy[base + i];
-        const int h = i / W, w = i - h * W;
+        const int h = fastdiv(i, divW), w = i - h * W;
         const size_t pq = (size_t)plane * (HW >> 2) + (size_t)((h >> 1) * (W >> 1) + (w >> 1));
         return pidx[pq] == (unsigned char)((h & 1) * 2 + (w & 1)) ? dy[pq] : 0.f;
     };
@@ -2076,6 +2079,7 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
     q.O = g->O; q.C = g->C; q.T = g->kh * g->kw; q.P = pl.P; q.hb = b->act != KAN_ACT_NONE; q.nb = b->n_basis;
     q.IPC = flat ? 1 : pl.IPC; q.KC = flat ? pl.P : pl.KC; q.Opad = pl.Opad;
     q.pair = (!flat && halo_fwd(g, b)) ? 1 : 0;
+    q.divT = make_fastdiv(q.T); q.divNb = make_fastdiv(q.nb); q.divIPC = make_fastdiv(q.IPC); q.divP = make_fastdiv(q.P);
     return q;
 }
 
@@ -2085,7 +2089,7 @@ void launch_in_fwd(hipStream_t st, int planes, const float* z, int n_slabs, long
                    unsigned char* pidx = nullptr, int W = 0) {
     int ppb = 256 / G;
     hipLaunchKernelGGL((k_in_prelu_fwd<G>), dim3(ceil_div(planes, ppb)), dim3(256), 0, st, z, n_slabs, slab_elems, z_out, gamma, beta, a, y,
-                       mean, rstd, planes, Cn, HW, bs, eps, span, pidx, W);
+                       mean, rstd, planes, Cn, HW, bs, eps, span, pidx, W, make_fastdiv(W > 1 ? W / 2 : 1));
 }
 template <int G>
 void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
@@ -2096,7 +2100,7 @@ void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, 
     const int cap = (long long)planes * HW < (4ll << 20) ? 512 : 2048;       // small tensors: fewer same-address atomics on dprelu
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
-                       dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W);
+                       dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, make_fastdiv(W > 0 ? W : 1));
 }
 // Lanes per (b, channel) plane.
 int group_lanes(int HW) {          // (more elements per lane was measured: no gain)

@@ -13,6 +13,7 @@ import torch.nn as nn
 
 from .conv_layers import ChebyKANConv2DLayer, FastKANConv2DLayer, KANConv2DLayer
 from .relu_layers import ReLUKANConv2DLayer
+from ..utils.regularization import L1
 from .gram_layers import GRAMKANConv2DLayer
 from .poly_layers import (BersnsteinKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, LegendreKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
                           JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
@@ -28,10 +29,9 @@ def _calculate_same_padding(kernel_size: _IntOrPair, dilation: _IntOrPair) -> _I
     return ph if (ph == pw and kh == kw) else (ph, pw)
 
 
-def _no_l1(l1_decay: float):
-    if l1_decay > 0:
-        raise NotImplementedError("l1_decay > 0 wraps the layer in utils.regularization.L1 in the reference; that module is "
-                                  "outside the accelerated path -- wrap the returned layer yourself")
+def _l1(l1_decay: float, layer: nn.Module) -> nn.Module:
+    """layers/kan_conv.py:66-68 (and every sibling factory): `if l1_decay > 0: conv = L1(conv, l1_decay)`."""
+    return L1(layer, l1_decay) if l1_decay > 0 else layer
 
 
 def kan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, spline_order: int = 3, groups: int = 1,
@@ -41,11 +41,10 @@ def kan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, spline_or
              norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> KANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return KANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, spline_order=spline_order,
+    return _l1(l1_decay, KANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, spline_order=spline_order,
                           stride=stride, padding=padding, dilation=dilation, groups=groups, grid_size=grid_size,
                           base_activation=base_activation, grid_range=grid_range, dropout=dropout, norm_layer=norm_layer,
-                          **norm_kwargs)
+                          **norm_kwargs))
 
 
 def chebykan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, degree: int = 3, groups: int = 1,
@@ -54,10 +53,9 @@ def chebykan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, degr
                   norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> ChebyKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return ChebyKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
+    return _l1(l1_decay, ChebyKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
                                padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer,
-                               **norm_kwargs)
+                               **norm_kwargs))
 
 
 def fastkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -67,11 +65,11 @@ def fastkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, group
                  **norm_kwargs) -> FastKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    # the reference forwards l1_decay into **norm_kwargs, where the signature filter drops it (kan_conv.py:258-272)
-    return FastKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
-                              dilation=dilation, groups=groups, grid_size=grid_size, base_activation=base_activation,
-                              grid_range=grid_range, dropout=dropout, l1_decay=l1_decay, norm_layer=norm_layer, **norm_kwargs)
+    # the reference also forwards l1_decay into **norm_kwargs, where the signature filter drops it (kan_conv.py:258-272)
+    return _l1(l1_decay, FastKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, stride=stride,
+                                            padding=padding, dilation=dilation, groups=groups, grid_size=grid_size,
+                                            base_activation=base_activation, grid_range=grid_range, dropout=dropout, l1_decay=l1_decay,
+                                            norm_layer=norm_layer, **norm_kwargs))
 
 
 def conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -82,10 +80,9 @@ def conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int =
     """Plain [Dropout] -> Conv2d -> [norm] -> [activation] block (kan_conv.py:71-116); not on the KAN path, torch ops only."""
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
     mods = [nn.Dropout(p=dropout)] if dropout > 0 else []
-    mods.append(nn.Conv2d(in_planes, out_planes, kernel_size, stride=stride, padding=padding, dilation=dilation, groups=groups,
-                          bias=norm_layer is None))
+    mods.append(_l1(l1_decay, nn.Conv2d(in_planes, out_planes, kernel_size, stride=stride, padding=padding, dilation=dilation,
+                                        groups=groups, bias=norm_layer is None)))          # kan_conv.py:105-108: L1 around the Conv2d only
     if norm_layer is not None:
         mods.append(norm_layer(out_planes))
     if base_activation is not None:
@@ -103,9 +100,8 @@ def legendrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, d
     """kan_conv.py:120-155 (this one does forward `dilation`)."""
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return LegendreKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
-                                  padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer, **norm_kwargs)
+    return _l1(l1_decay, LegendreKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
+                                  padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer, **norm_kwargs))
 
 
 def bersnsteinkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -115,10 +111,9 @@ def bersnsteinkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair,
     """kan_conv.py:319-351 (forwards `dilation`; `l1_decay` rides in **norm_kwargs and is filtered out)."""
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return BersnsteinKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, BersnsteinKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                     stride=stride, padding=padding, dilation=dilation, dropout=dropout, l1_decay=l1_decay,
-                                    norm_layer=norm_layer, **norm_kwargs)
+                                    norm_layer=norm_layer, **norm_kwargs))
 
 
 def besselkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -127,10 +122,9 @@ def besselkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gro
                    norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> BesselKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return BesselKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, BesselKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                 padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
-                                norm_layer=norm_layer, **norm_kwargs)
+                                norm_layer=norm_layer, **norm_kwargs))
 
 
 def fibonaccikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -139,10 +133,9 @@ def fibonaccikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, 
                       norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> FibonacciKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return FibonacciKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, FibonacciKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                    padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
-                                   norm_layer=norm_layer, **norm_kwargs)
+                                   norm_layer=norm_layer, **norm_kwargs))
 
 
 def fourierkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -151,10 +144,9 @@ def fourierkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gr
                     norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> FourierKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return FourierKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, grid_size=grid_size, groups=groups,
+    return _l1(l1_decay, FourierKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, grid_size=grid_size, groups=groups,
                                  padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
-                                 norm_layer=norm_layer, **norm_kwargs)
+                                 norm_layer=norm_layer, **norm_kwargs))
 
 
 def gegenbauerkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -163,10 +155,9 @@ def gegenbauerkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair,
                        norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> GegenbauerKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return GegenbauerKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, GegenbauerKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                     padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, alpha_param=alpha_param,
-                                    base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+                                    base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs))
 
 
 def hermitekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -175,10 +166,9 @@ def hermitekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gr
                     norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> HermiteKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return HermiteKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, HermiteKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                  padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
-                                 norm_layer=norm_layer, **norm_kwargs)
+                                 norm_layer=norm_layer, **norm_kwargs))
 
 
 def jacobikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -187,10 +177,9 @@ def jacobikan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gro
                    norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> JacobiKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return JacobiKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, a=a, b=b,
+    return _l1(l1_decay, JacobiKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, a=a, b=b,
                                 groups=groups, padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout,
-                                base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+                                base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs))
 
 
 def relukan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -201,10 +190,9 @@ def relukan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, group
     default dilation 1."""
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return ReLUKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, g=g, k=k, train_ab=train_ab,
+    return _l1(l1_decay, ReLUKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, g=g, k=k, train_ab=train_ab,
                               groups=groups, padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout,
-                              base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+                              base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs))
 
 
 def gramkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, degree: int = 3, groups: int = 1, stride: _IntOrPair = 1,
@@ -214,9 +202,8 @@ def gramkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, degre
     """layers/kan_conv.py:158-194 (no base_activation argument: the 2-D GRAM layer always runs SiLU)."""
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return GRAMKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
-                              padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer, **norm_kwargs)
+    return _l1(l1_decay, GRAMKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, stride=stride,
+                              padding=padding, dilation=dilation, groups=groups, dropout=dropout, norm_layer=norm_layer, **norm_kwargs))
 
 
 def laguerrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -225,10 +212,9 @@ def laguerrekan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, g
                      norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> LaguerreKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return LaguerreKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, alpha=alpha,
+    return _l1(l1_decay, LaguerreKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, alpha=alpha,
                                   groups=groups, padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout,
-                                  base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs)
+                                  base_activation=base_activation, norm_layer=norm_layer, **norm_kwargs))
 
 
 def lucaskan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -237,10 +223,9 @@ def lucaskan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, grou
                   norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> LucasKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return LucasKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, LucasKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                padding=padding, stride=stride, l1_decay=l1_decay, dropout=dropout, base_activation=base_activation,
-                               norm_layer=norm_layer, **norm_kwargs)
+                               norm_layer=norm_layer, **norm_kwargs))
 
 
 def taylorkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
@@ -249,10 +234,9 @@ def taylorkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gro
                    norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> TaylorKANConv2DLayer:
     if padding is None:
         padding = _calculate_same_padding(kernel_size, dilation)
-    _no_l1(l1_decay)
-    return TaylorKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
+    return _l1(l1_decay, TaylorKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, degree=degree, groups=groups,
                                 padding=padding, stride=stride, dropout=dropout, base_activation=base_activation, norm_layer=norm_layer,
-                                **norm_kwargs)
+                                **norm_kwargs))
 
 
 

@@ -291,3 +291,22 @@ def test_vgg_fused_pool_matches_unfused_model(gpu_lib):
     assert relerr(res[0][0], res[1][0]) <= 1e-6
     for a, b in zip(res[0][1], res[1][1]):
         assert relerr(a, b) <= 1e-5
+
+
+def test_l1_wrapped_layer_runs_on_the_hip_path(gpu_lib):
+    """kan_conv.py:66-68 wraps the layer in L1 when l1_decay > 0; the wrapper's full backward hook must coexist with the
+    custom autograd functions.  Every gradient is the plain one, or the plain one plus l1_decay * sign(p) where the hook
+    found the gradient still empty (utils/regularization.py:79-83)."""
+    torch.manual_seed(0)
+    w = K.CONV_KAN_FACTORY["KAN"](3, 8, 3, l1_decay=0.1).cuda()
+    x = torch.randn(2, 3, 8, 8, device="cuda", requires_grad=True)
+    go = torch.randn(2, 8, 8, 8, device="cuda")
+    w.module(x).backward(go)
+    plain = {n: p.grad.clone() for n, p in w.module.named_parameters()}
+    w.module.zero_grad(set_to_none=True)
+    y = w(x)
+    assert torch.equal(y, w.module(x))
+    y.backward(go)
+    for n, p in w.module.named_parameters():
+        pen = 0.1 * torch.sign(p.detach())
+        assert relerr(p.grad, plain[n]) <= 1e-6 or relerr(p.grad, plain[n] + pen) <= 1e-6, n

@@ -214,8 +214,10 @@ def test_factory_signatures_and_same_padding():
     assert F["KAN"](3, 8, 3).padding == 1 and F["KAN"](3, 8, 5, dilation=2).padding == 4
     assert F["KAN"](3, 8, (3, 5)).padding == (1, 2)
     assert F["FastKAN"](3, 8, 3, l1_decay=0.0).padding == 1 and F["ChebyKAN"](3, 8, 3, degree=4, affine=True).layer_norm[0].affine
-    with pytest.raises(NotImplementedError):
-        F["KAN"](3, 8, 3, l1_decay=0.1)
+    wrapped = F["KAN"](3, 8, 3, l1_decay=0.1)                    # kan_conv.py:66-68: L1(conv, l1_decay)
+    assert type(wrapped).__name__ == "L1" and isinstance(wrapped.module, K.KANConv2DLayer) and wrapped.weight_decay == 0.1
+    assert list(wrapped.state_dict())[0] == "module.base_conv.0.weight"
+    assert type(F["LucasKAN"](4, 6, 3, l1_decay=0.01)).__name__ == "L1" and type(F["conv"](3, 8, 3, l1_decay=0.1)[0]).__name__ == "L1"
     with pytest.raises(NotImplementedError, match="HIP functor"):
         K.KANConv2DLayer(3, 4, 3, base_activation=nn.Softplus)
 
@@ -240,3 +242,32 @@ def test_models_build_with_reference_parameter_names():
     assert [n for n, _ in m.named_parameters()] == names and sum(p.numel() for p in m.parameters()) == 82964690
     a = alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4, arch="small")
     assert a.features[0].kernel_size == 5 and a.features[0].layer_norm[0].affine
+
+
+def test_l1_l2_wrapper_hook_semantics():
+    """utils/regularization.py:57-159: a full backward hook on the wrapped module that seeds .grad with the penalty for every
+    selected parameter whose gradient is still None or all zeros when it fires, and leaves real gradients alone."""
+    from convkan_amd.utils import L1, L2
+    torch.manual_seed(0)
+    lin = nn.Linear(5, 3)
+    for cls, pen in ((L1, lambda p: 0.1 * torch.sign(p)), (L2, lambda p: 0.1 * p)):
+        w = cls(lin, 0.1)
+        assert len(lin._backward_hooks) == 1 and list(w.state_dict()) == ["module.weight", "module.bias"]
+        lin.zero_grad(set_to_none=True)
+        w._weight_decay_hook()                                               # gradients still None
+        assert all(torch.equal(p.grad, pen(p.detach())) for p in lin.parameters())
+        lin.weight.grad = torch.zeros_like(lin.weight); lin.bias.grad = torch.ones_like(lin.bias)
+        w._weight_decay_hook()                                               # all-zero -> penalty; non-zero -> untouched
+        assert torch.equal(lin.weight.grad, pen(lin.weight.detach())) and torch.equal(lin.bias.grad, torch.ones(3))
+        w.remove()
+        assert len(lin._backward_hooks) == 0
+    lin.zero_grad(set_to_none=True)
+    only_w = L1(lin, 0.5, name="weight")
+    only_w._weight_decay_hook()
+    assert lin.bias.grad is None and torch.equal(lin.weight.grad, 0.5 * torch.sign(lin.weight.detach()))
+    x = torch.randn(4, 5, requires_grad=True)
+    assert torch.equal(only_w(x), lin(x))
+    only_w(x).sum().backward()                                               # the hook is live in a real backward pass
+    assert lin.bias.grad is not None
+    with pytest.raises(ValueError):
+        L1(lin, -1.0)

@@ -121,6 +121,11 @@ def cpu_baseline(batch: int, iters: int):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON).  Native libraries print banners there (RCCL: "RCCL version : ..." at
+    # communicator creation), so fd 1 points at stderr until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -223,7 +228,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)                                     # anything printed during teardown goes to stderr again
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

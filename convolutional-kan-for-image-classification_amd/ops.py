@@ -229,8 +229,30 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     return z, (wd, x_pm), geom, basis, plan
 
 
-def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool, phases=None, mode: int = 0):
-    """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list) -- per-group views of stacked gradients."""
+# --------------------------------------------------------------------------------------- gradient sinks (data parallel)
+# parallel/dp.py registers, per weight Parameter, the slice of its all-reduce bucket.  The weight-gradient unpack kernel
+# then writes the reference-layout gradient straight into the bucket and autograd adopts that view as .grad: the copy
+# "gradient -> bucket" (332 MB read + write per KAN-VGG11 step) disappears.  Single-group layers only (grouped layers
+# stack their per-group gradients in one tensor and keep the copy).
+GRAD_SINKS: "dict[int, tuple]" = {}                # id(Parameter) -> (weakref to it, bucket view of its shape)
+
+
+def _sink_for(wid, shape, device):
+    ent = GRAD_SINKS.get(wid) if wid is not None else None
+    if ent is None:
+        return None
+    ref, t = ent
+    p = ref()
+    # only a FIRST gradient may be written in place: with .grad already set autograd accumulates, and the sink would
+    # have overwritten the running sum
+    if p is None or p.grad is not None or tuple(t.shape) != tuple(shape) or t.device != device or not t.is_contiguous():
+        return None
+    return t
+
+
+def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool, phases=None, mode: int = 0, wids=None):
+    """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list) -- per-group views of stacked gradients.
+    `wids`: ids of the (base, basis) weight Parameters of a single-group layer, for GRAD_SINKS."""
     lib = L.load()
     B, Ct, H, W = x.shape
     G = spec.groups
@@ -251,8 +273,11 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
                 lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
                                                 _ptr(dz_pm), st))
-        dwb = torch.empty((G, Og, Cg, kh, kw), device=x.device, dtype=torch.float32) if spec.has_base else None
-        dws = torch.empty((G, Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
+        sb = _sink_for(wids[0], (Og, Cg, kh, kw), x.device) if (wids and G == 1 and spec.has_base) else None
+        ss = _sink_for(wids[1], (Og, Cg * spec.n_basis, kh, kw), x.device) if (wids and G == 1) else None
+        dwb = (sb.unsqueeze(0) if sb is not None else
+               torch.empty((G, Og, Cg, kh, kw), device=x.device, dtype=torch.float32)) if spec.has_base else None
+        dws = ss.unsqueeze(0) if ss is not None else torch.empty((G, Og, Cg * spec.n_basis, kh, kw), device=x.device, dtype=torch.float32)
         L.check(lib.kan_unpack_wgrad(_ptr(dwp), _ptr(dwb), _ptr(dws), C.byref(geom), C.byref(basis), st), "kan_unpack_wgrad")
         dw_basis = list(dws.unbind(0))
         if spec.has_base:
@@ -427,6 +452,7 @@ class _KanConvInPrelu(torch.autograd.Function):
                         "kan_instnorm_prelu_fwd")
         z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
         ctx.spec, ctx.flags = spec, (use_affine, use_prelu, pool)
+        ctx.wids = (id(w_base[0]) if spec.has_base else None, id(w_basis[0])) if G == 1 else None
         ctx.layout = (packed[0] is not None, packed[1] is not None)
         ctx.save_for_backward(x, z, mean, rstd, *[t for t in packed if t is not None], *[t for t in (gamma, beta, slope) if t is not None],
                               *([pidx] if pool else []))
@@ -467,7 +493,7 @@ class _KanConvInPrelu(torch.autograd.Function):
             nw = G * (2 if spec.has_base else 1)
             need_x = ctx.needs_input_grad[5]
             need_w = any(ctx.needs_input_grad[6:6 + nw])
-            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w)
+            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w, wids=ctx.wids)
         grads = _flat_grads(spec, dwb, dws)
         if use_affine:
             grads += tuple(dgam.view(G, Og).unbind(0)) + tuple(dbet.view(G, Og).unbind(0))

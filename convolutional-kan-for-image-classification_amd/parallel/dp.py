@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional
 
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -62,11 +64,22 @@ class BucketedGradReducer:
         self.avg_in_collective = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
         self.side = torch.cuda.Stream(device=plist[0].device) if self.cuda else None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in plist]
+        # conv-KAN weights: let the weight-gradient kernels write into the bucket directly (ops.GRAD_SINKS); the hook then
+        # finds .grad already in place and skips its copy
+        self._sinks = []
+        if self.cuda:
+            from .. import ops
+            for b in self.buckets:
+                for v, p in zip(b.views, b.params):
+                    if p.dim() == 4:
+                        ops.GRAD_SINKS[id(p)] = (weakref.ref(p), v)
+                        self._sinks.append(id(p))
 
     # -- called by autograd right after p.grad has been written
     def _on_grad(self, p: torch.nn.Parameter):
         b, i = self._where[p]
-        b.views[i].copy_(p.grad)
+        if p.grad.data_ptr() != b.views[i].data_ptr():      # (already there when the kernel wrote through a gradient sink)
+            b.views[i].copy_(p.grad)
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -105,3 +118,8 @@ class BucketedGradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        if self._sinks:
+            from .. import ops
+            for k in self._sinks:
+                ops.GRAD_SINKS.pop(k, None)
+            self._sinks = []

@@ -104,3 +104,43 @@ def test_training_step_is_bitwise_deterministic(gpu_lib):
         assert torch.equal(runs[0][1], runs[k][1]), "input gradient differs between identical runs"
         for n, g in runs[0][2].items():
             assert torch.equal(g, runs[k][2][n]), f"{n} gradient differs between identical runs"
+
+
+def test_gradient_sinks_write_into_the_reducer_buckets(gpu_lib):
+    """parallel/dp.py registers bucket slices as gradient sinks: the weight-gradient unpack writes there, autograd adopts the
+    view as .grad (no gradient -> bucket copy), values are unchanged, and accumulation over two backward passes still sums."""
+    import torch.nn as nn
+    import convkan_amd as K
+    from convkan_amd.parallel import BucketedGradReducer
+    torch.manual_seed(0)
+    net = nn.Sequential(K.KANConv2DLayer(4, 128, 3, padding=1), K.KANConv2DLayer(128, 8, 3, padding=1, groups=2)).cuda()
+    x = torch.randn(3, 4, 8, 8, device="cuda")
+    net(x).square().mean().backward()
+    plain = [p.grad.clone() for p in net.parameters()]
+    net.zero_grad(set_to_none=True)
+    red = BucketedGradReducer(net.parameters())
+    try:
+        net(x).square().mean().backward()
+        red.finish()
+        views = {id(p): v for b in red.buckets for p, v in zip(b.params, b.views)}
+        in_place = 0
+        for (n, p), g in zip(net.named_parameters(), plain):
+            err = float((p.grad - g).abs().max()) / (float(g.abs().max()) + 1e-30)
+            assert err <= (0.0 if p.dim() == 4 else 1e-5), (n, err)           # PReLU slopes sum with float atomics
+            assert p.grad.data_ptr() == views[id(p)].data_ptr(), n            # finish() publishes the bucket views
+        net.zero_grad(set_to_none=True)
+        hits = []
+        hooks = [p.register_post_accumulate_grad_hook(lambda q: hits.append(q.grad.data_ptr() == views[id(q)].data_ptr())) for p in net[0].parameters()
+                 if p.dim() == 4]
+        net(x).square().mean().backward()
+        assert hits and all(hits)                                             # single-group conv weights arrived in place
+        net(x).square().mean().backward()                                     # second pass accumulates (no sink: .grad is set)
+        red.finish()
+        for h in hooks:
+            h.remove()
+        for p, g in zip(net.parameters(), plain):
+            assert float((p.grad - 2 * g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-12
+    finally:
+        red.remove()
+    from convkan_amd import ops
+    assert not ops.GRAD_SINKS

@@ -100,7 +100,10 @@ def _check(layer, cfg, x, c):
     assert not bad, f"{c}: {bad}"
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KAN_FUZZ_N", "60"))))
+_OFF = int(__import__("os").environ.get("KAN_FUZZ_OFFSET", "0"))      # KAN_FUZZ_OFFSET / _N / _FAM_N: explore other seed ranges
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + int(__import__("os").environ.get("KAN_FUZZ_N", "60"))))
 def test_random_geometry_vs_oracle(seed, gpu_lib):
     """Tolerance per tensor = max(stated, 4 x the oracle's own fp32-vs-fp64 difference on that tensor) -- the rule of the golden
     fixtures -- so that draws the reference itself cannot reproduce (InstanceNorm over near-constant or mostly-padding planes)

@@ -92,7 +92,7 @@ def _check(layer, cfg, x, c):
         if p_.numel() == 1:                                       # per-group PReLU slopes: judged together (one scalar each)
             scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dw32[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
         else:
-            errs[name] = (relerr(p_.grad, dw32[name]), tol(TOL_DW if p_.dim() >= 4 else 2e-5, dw32[name], dw64[name]))
+            errs[name] = (relerr(p_.grad, dw32[name]), tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
     if scal_h:
         a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
         errs["prelus"] = (relerr(a, b), tol(2e-5, b, b64))
@@ -159,3 +159,32 @@ def test_random_family_vs_oracle(seed, gpu_lib):
                 m.weight.add_(0.2 * torch.randn_like(m.weight)); m.bias.add_(0.2 * torch.randn_like(m.bias))
     x = torch.randn(B, C, H, H) * (1.0 + (seed % 2))
     _check(layer, cfg, x, dict(fam=fam, C=C, O=O, G=G, H=H, W=H, B=B, affine=affine))
+
+
+ONE_D = {"bspline": "KANConv1DLayer", "rbf": "FastKANConv1DLayer", "cheby": "ChebyKANConv1DLayer", "relu": "ReLUKANConv1DLayer"}
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + int(__import__("os").environ.get("KAN_FUZZ_1D_N", "24"))))
+def test_random_1d_vs_oracle(seed, gpu_lib):
+    """The 1-D shims ([B, C, L] lifted to [B, C, 1, L] on the 2-D kernels: kan_layers.py:287-297 and siblings) over random
+    lengths, kernels, strides, dilations and groups."""
+    r = random.Random(9000 + seed)
+    kind = list(ONE_D)[seed % len(ONE_D)]
+    G = r.choice([1, 1, 2, 3])
+    C, O = r.choice([1, 2, 3, 8]) * G, r.choice([1, 4, 16, 64, 128]) * G
+    k = r.choice([1, 3, 3, 5, 7])
+    s_, d = r.choice([1, 1, 2, 3]), r.choice([1, 1, 2])
+    p = r.choice([0, 1, d * (k - 1) // 2, d * (k - 1)])
+    Lx = r.choice([4, 9, 16, 33, 64, 200, 1000])
+    if (Lx + 2 * p - d * (k - 1) - 1) // s_ + 1 < 4:                    # keep >= 4 outputs (InstanceNorm over 1-3 values: see above)
+        p, s_ = d * (k - 1), 1
+    B = r.choice([1, 2, 5, 16]) if O * Lx <= 65536 else r.choice([1, 2])
+    torch.manual_seed(seed)
+    kw = dict(groups=G, stride=s_, dilation=d, padding=p)
+    layer = getattr(K, ONE_D[kind])(C, O, k, **kw)
+    cfg = _cfg(kind, C, O, k=k, s=s_, p=p, d=d, groups=G, degree=3, ndim=1, act="gelu" if kind == "bspline" else "silu")
+    if kind == "relu":
+        with torch.no_grad():
+            layer.phase_low.add_(0.05 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.05 * torch.randn_like(layer.phase_high))
+    x = torch.randn(B, C, Lx) * (1.0 + (seed % 2))
+    _check(layer, cfg, x, dict(kind=kind, C=C, O=O, G=G, H=1, W=Lx, k=k, s=s_, d=d, p=p, B=B))

@@ -15,7 +15,8 @@ between this package and the reference in both directions, and keeps callers tha
 
 The 2-D layers are the hot path.  The 1-D shims (KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv1DLayer:
 kan_layers.py:287-297, fast_kan_layers.py:151-162, cheby_kan_layers.py:134-141) run on the same kernels by viewing
-[B, C, L] as [B, C, 1, L] with a (1, k) kernel; 3-D layers are not built.
+[B, C, L] as [B, C, 1, L] with a (1, k) kernel; the 3-D shims (kan_layers.py:261-271 and siblings) run one 2-D launch set per
+depth tap (conv3d_stage).
 """
 from __future__ import annotations
 
@@ -56,7 +57,7 @@ def _act_code(module: nn.Module) -> int:
 def _dropout2d(p: float, ndim: int = 2):
     if p <= 0:
         return None
-    return nn.Dropout1d(p=p) if ndim == 1 else nn.Dropout2d(p=p)
+    return nn.Dropout1d(p=p) if ndim == 1 else nn.Dropout3d(p=p) if ndim == 3 else nn.Dropout2d(p=p)
 
 
 def _check_groups(groups, input_dim, output_dim):
@@ -79,9 +80,69 @@ def _fusable_instnorm(mods) -> bool:
     return all(type(m) in (nn.InstanceNorm2d, nn.InstanceNorm1d) and not m.track_running_stats for m in mods)
 
 
-def _need_conv2d(conv_class, ndim):
-    if (conv_class, ndim) not in ((nn.Conv2d, 2), (nn.Conv1d, 1)):
-        raise NotImplementedError("the HIP path implements the 1-D and 2-D layers (3-D: SURVEY.md 8(f))")
+def _need_conv2d(conv_class, ndim, allow_3d: bool = False):
+    ok = ((nn.Conv2d, 2), (nn.Conv1d, 1)) + (((nn.Conv3d, 3),) if allow_3d else ())
+    if (conv_class, ndim) not in ok:
+        raise NotImplementedError("this layer is built for " + ("1-D, 2-D and 3-D" if allow_3d else "1-D and 2-D") + " on the HIP path")
+
+
+def _triple(v):
+    if isinstance(v, (tuple, list)):
+        if len(v) != 3:
+            raise ValueError(f"expected an int or a triple, got {v!r}")
+        return int(v[0]), int(v[1]), int(v[2])
+    return int(v), int(v), int(v)
+
+
+def conv3d_stage(basis_kw, kernel_size, stride, padding, dilation, groups, x, xn, w_base, w_basis):
+    """The fused conv stage for 3-D layers (kan_layers.py:261-271 and the sibling 3-D shims), on the 2-D kernels.
+
+    A 3-D cross-correlation is a sum over the kd depth taps of 2-D ones: output slice `do` takes, for tap `td`, the 2-D
+    conv stage of input slice `di = do*sd - pd + td*dd` with the kernel slice W[:, :, td] -- and nothing where `di` falls into
+    the depth padding, which is exactly the reference's zero padding of the EXPANDED operand.  So each depth tap is one
+    launch set of the 2-D kernels over the batch of all (image, valid depth slice) pairs; torch only gathers the slices and
+    sums the kd partial results.  x: [B, C, D, H, W]; weights per group [Og, Cg(*n), kd, kh, kw]."""
+    (kd, kh, kw), (sd, sh, sw), (pd, ph, pw), (dd, dh, dw) = _triple(kernel_size), _triple(stride), _triple(padding), _triple(dilation)
+    if x.dim() != 5:
+        raise ValueError(f"expected [B, C, D, H, W] input for a 3-D layer, got shape {tuple(x.shape)}")
+    B, C, D, H, W = x.shape
+    Do = (D + 2 * pd - dd * (kd - 1) - 1) // sd + 1
+    if Do <= 0:
+        raise L.KanConvError(f"empty output depth for input depth {D}")
+    spec = ops.ConvSpec(kernel=(kh, kw), stride=(sh, sw), padding=(ph, pw), dilation=(dh, dw), groups=groups, **basis_kw)
+    z = None
+    for td in range(kd):
+        dos = [o for o in range(Do) if 0 <= o * sd - pd + td * dd < D]
+        if not dos:
+            continue
+        d0, n = dos[0] * sd - pd + td * dd, len(dos)              # valid outputs are consecutive; their inputs step by sd
+
+        def gather(t):
+            return t[:, :, d0:d0 + (n - 1) * sd + 1:sd].permute(0, 2, 1, 3, 4).reshape(B * n, C, H, W)
+        z2 = ops.kan_conv(spec, gather(x), gather(xn) if xn is not None else None,
+                          [w[:, :, td] for w in w_base], [w[:, :, td] for w in w_basis])
+        z2 = z2.view(B, n, *z2.shape[1:]).permute(0, 2, 1, 3, 4)                      # [B, O, n, Ho, Wo]
+        z2 = F.pad(z2, (0, 0, 0, 0, dos[0], Do - dos[0] - n))
+        z = z2 if z is None else z + z2
+    if z is None:
+        raise L.KanConvError("no depth tap reaches the input (kernel entirely inside the depth padding)")
+    return z
+
+
+def _norm3d(mods, prelus, z, og):
+    """Per-group norm (+ PReLU) of a [B, O, D, H, W] tensor: plain InstanceNorm3d runs on the InstanceNorm kernel with the
+    volume as one plane; anything else is the caller's own module."""
+    if all(type(m) is nn.InstanceNorm3d and not m.track_running_stats for m in mods):
+        B, O, Dz, Hz, Wz = z.shape
+        gam = torch.cat([m.weight for m in mods]) if mods[0].affine else None
+        bet = torch.cat([m.bias for m in mods]) if mods[0].affine else None
+        y = ops.instance_norm(z.reshape(B, O, Dz * Hz, Wz), gam, bet, eps=mods[0].eps).view(B, O, Dz, Hz, Wz)
+        parts = [y[:, g * og:(g + 1) * og] for g in range(len(mods))]
+    else:
+        parts = [mods[g](z[:, g * og:(g + 1) * og]) for g in range(len(mods))]
+    if prelus is not None:
+        parts = [prelus[g](p) for g, p in enumerate(parts)]
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
 def _one(v):
@@ -130,7 +191,7 @@ class KANConvNDLayer(_HipLayer):
                  ndim: int = 2, grid_size=5, base_activation=nn.GELU, grid_range=[-1, 1], dropout=0.0,
                  **norm_kwargs):
         super().__init__()
-        _need_conv2d(conv_class, ndim)
+        _need_conv2d(conv_class, ndim, allow_3d=True)
         self.input_dim, self.output_dim = input_dim, output_dim
         self.spline_order, self.kernel_size = spline_order, kernel_size
         self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
@@ -160,13 +221,26 @@ class KANConvNDLayer(_HipLayer):
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         self._act_code = _act_code(self.base_activation)
 
+    def _basis_kw(self):
+        return dict(kind=L.BASIS_BSPLINE, n_basis=self.grid_size + self.spline_order, order=self.spline_order,
+                    act=self._act_code, p0=0.0, p1=0.0, table=tuple(float(v) for v in self.grid.tolist()))
+
     def conv_spec(self) -> ops.ConvSpec:
-        return self._spec(kind=L.BASIS_BSPLINE, n_basis=self.grid_size + self.spline_order, order=self.spline_order,
-                          act=self._act_code, p0=0.0, p1=0.0, table=tuple(float(v) for v in self.grid.tolist()))
+        return self._spec(**self._basis_kw())
+
+    def _forward3d(self, x):
+        z = conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, x, None,
+                         [m.weight for m in self.base_conv], [m.weight for m in self.spline_conv])
+        y = _norm3d(self.layer_norm, self.prelus, z, self.output_dim_group)
+        return self.dropout(y) if self.dropout is not None else y
 
     def forward(self, x, pool: bool = False):
         """`pool=True` (not part of the reference signature; used by models/kan_vgg.py for a layer that is followed by
         MaxPool2d(2, 2)) returns max_pool2d(layer(x), 2, 2) with the pooling done inside the InstanceNorm+PReLU kernels."""
+        if self.ndim == 3:
+            if pool:
+                raise NotImplementedError("pool=True is a 2-D fusion")
+            return self._forward3d(x)
         spec = self.conv_spec()
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.spline_conv)
@@ -186,6 +260,15 @@ class KANConvNDLayer(_HipLayer):
         if self.dropout is not None:
             y = self.dropout(y)
         return F.max_pool2d(y, 2, 2) if pool else y
+
+
+class KANConv3DLayer(KANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, spline_order=3, groups=1, padding=0, stride=1, dilation=1,
+                 grid_size=5, base_activation=nn.GELU, grid_range=[-1, 1], dropout=0.0, norm_layer=nn.InstanceNorm3d,
+                 **norm_kwargs):
+        super().__init__(nn.Conv3d, norm_layer, input_dim, output_dim, spline_order, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=3,
+                         grid_size=grid_size, base_activation=base_activation, grid_range=grid_range, dropout=dropout, **norm_kwargs)
 
 
 class KANConv1DLayer(KANConvNDLayer):
@@ -223,7 +306,7 @@ class FastKANConvNDLayer(_HipLayer):
                  groups=1, padding=0, stride=1, dilation=1,
                  ndim: int = 2, grid_size=8, base_activation=nn.SiLU, grid_range=[-2, 2], dropout=0.0, **norm_kwargs):
         super().__init__()
-        _need_conv2d(conv_class, ndim)
+        _need_conv2d(conv_class, ndim, allow_3d=True)
         self.input_dim, self.output_dim, self.kernel_size = input_dim, output_dim, kernel_size
         self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
         self.grid_size = grid_size
@@ -246,11 +329,29 @@ class FastKANConvNDLayer(_HipLayer):
         self._act_code = _act_code(self.base_activation)
         self._centres = tuple(float(v) for v in self.rbf.grid.detach().tolist())
 
+    def _basis_kw(self):
+        return dict(kind=L.BASIS_RBF, n_basis=self.grid_size, order=0, act=self._act_code, p0=float(self.rbf.denominator), p1=0.0,
+                    table=self._centres)
+
     def conv_spec(self) -> ops.ConvSpec:
-        return self._spec(kind=L.BASIS_RBF, n_basis=self.grid_size, order=0, act=self._act_code,
-                          p0=float(self.rbf.denominator), p1=0.0, table=self._centres)
+        return self._spec(**self._basis_kw())
+
+    def _forward3d(self, x):
+        xs = self.dropout(x) if self.dropout is not None else x
+        cg = self.input_dim // self.groups
+        if all(type(m) is nn.InstanceNorm3d and not m.track_running_stats for m in self.layer_norm):
+            B, C, D, H, W = xs.shape
+            gam = torch.cat([m.weight for m in self.layer_norm]) if self.layer_norm[0].affine else None
+            bet = torch.cat([m.bias for m in self.layer_norm]) if self.layer_norm[0].affine else None
+            xn = ops.instance_norm(xs.reshape(B, C, D * H, W), gam, bet, eps=self.layer_norm[0].eps).view(B, C, D, H, W)
+        else:
+            xn = torch.cat([self.layer_norm[g](xs[:, g * cg:(g + 1) * cg]) for g in range(self.groups)], dim=1)
+        return conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, x, xn,
+                            [m.weight for m in self.base_conv], [m.weight for m in self.spline_conv])
 
     def forward(self, x):
+        if self.ndim == 3:
+            return self._forward3d(x)
         # fast_kan_layers.py:100-111: the base branch sees raw x; the RBFs see norm(dropout(x))
         xs = self.dropout(x) if self.dropout is not None else x
         cg = self.input_dim // self.groups
@@ -277,6 +378,16 @@ class FastKANConv1DLayer(FastKANConvNDLayer):
                          dropout=dropout, **norm_kwargs)
 
 
+class FastKANConv3DLayer(FastKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, groups=1, padding=0, stride=1, dilation=1,
+                 grid_size=8, base_activation=nn.SiLU, grid_range=[-2, 2], dropout=0.0,
+                 norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(nn.Conv3d, norm_layer, input_dim, output_dim, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=3,
+                         grid_size=grid_size, base_activation=base_activation, grid_range=grid_range,
+                         dropout=dropout, **norm_kwargs)
+
+
 class FastKANConv2DLayer(FastKANConvNDLayer):
     def __init__(self, input_dim, output_dim, kernel_size, groups=1, padding=0, stride=1, dilation=1,
                  grid_size=8, base_activation=nn.SiLU, grid_range=[-2, 2], dropout=0.0,
@@ -292,7 +403,7 @@ class ChebyKANConvNDLayer(_HipLayer):
     def __init__(self, conv_class, norm_layer, input_dim, output_dim, degree, kernel_size,
                  groups=1, padding=0, stride=1, dilation=1, ndim: int = 2, dropout=0.0, **norm_kwargs):
         super().__init__()
-        _need_conv2d(conv_class, ndim)
+        _need_conv2d(conv_class, ndim, allow_3d=True)
         self.input_dim, self.output_dim, self.degree, self.kernel_size = input_dim, output_dim, degree, kernel_size
         self.padding, self.stride, self.dilation, self.groups, self.ndim = padding, stride, dilation, groups, ndim
         self.norm_kwargs = norm_kwargs
@@ -309,12 +420,20 @@ class ChebyKANConvNDLayer(_HipLayer):
             nn.init.normal_(conv.weight, mean=0.0, std=1 / (input_dim * (degree + 1) * kernel_size ** ndim))
             nn.init.kaiming_normal_(conv.weight, mode='fan_in', nonlinearity='relu')
 
-    def conv_spec(self) -> ops.ConvSpec:
+    def _basis_kw(self):
         lo = float(np.float32(-1 + self.epsilon))       # torch.clamp casts its Python-float bounds to fp32
         hi = float(np.float32(1 - self.epsilon))
-        return self._spec(kind=L.BASIS_CHEBY, n_basis=self.degree + 1, order=0, act=L.ACT_NONE, p0=lo, p1=hi, table=())
+        return dict(kind=L.BASIS_CHEBY, n_basis=self.degree + 1, order=0, act=L.ACT_NONE, p0=lo, p1=hi, table=())
+
+    def conv_spec(self) -> ops.ConvSpec:
+        return self._spec(**self._basis_kw())
 
     def forward(self, x):
+        if self.ndim == 3:
+            z = conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, x, None, [],
+                             [m.weight for m in self.poly_conv])
+            y = _norm3d(self.layer_norm, None, z, self.output_dim // self.groups)
+            return self.dropout(y) if self.dropout is not None else y
         spec = self.conv_spec()
         x = self._lift(x)
         wp = self._w(self.poly_conv)
@@ -337,6 +456,13 @@ class ChebyKANConv1DLayer(ChebyKANConvNDLayer):
                          groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=1, dropout=dropout, **norm_kwargs)
 
 
+class ChebyKANConv3DLayer(ChebyKANConvNDLayer):
+    def __init__(self, input_dim, output_dim, kernel_size, degree=3, groups=1, padding=0, stride=1, dilation=1,
+                 dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(nn.Conv3d, norm_layer, input_dim, output_dim, degree, kernel_size,
+                         groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=3, dropout=dropout, **norm_kwargs)
+
+
 class ChebyKANConv2DLayer(ChebyKANConvNDLayer):
     def __init__(self, input_dim, output_dim, kernel_size, degree=3, groups=1, padding=0, stride=1, dilation=1,
                  dropout=0.0, norm_layer=nn.InstanceNorm2d, **norm_kwargs):
@@ -344,6 +470,6 @@ class ChebyKANConv2DLayer(ChebyKANConvNDLayer):
                          groups=groups, padding=padding, stride=stride, dilation=dilation, ndim=2, dropout=dropout, **norm_kwargs)
 
 
-__all__ = ["KANConvNDLayer", "KANConv2DLayer", "KANConv1DLayer", "FastKANConvNDLayer", "FastKANConv2DLayer", "FastKANConv1DLayer",
+__all__ = ["KANConvNDLayer", "KANConv2DLayer", "KANConv1DLayer", "KANConv3DLayer", "FastKANConv3DLayer", "ChebyKANConv3DLayer", "FastKANConvNDLayer", "FastKANConv2DLayer", "FastKANConv1DLayer",
            "ChebyKANConvNDLayer", "ChebyKANConv2DLayer", "ChebyKANConv1DLayer", "RadialBasisFunction"]
 _ = F

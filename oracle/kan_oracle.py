@@ -96,7 +96,8 @@ def _per_group(x: Tensor, groups: int, fn: Callable[[Tensor, int], Tensor]) -> T
 
 
 def _conv(x, w, stride, padding, dilation):
-    return F.conv2d(x, w, None, stride, padding, dilation, 1)
+    """conv2d; conv3d for the 3-D shims (kan_layers.py:261-271: the same layer with nn.Conv3d / InstanceNorm3d)."""
+    return (F.conv3d if w.dim() == 5 else F.conv2d)(x, w, None, stride, padding, dilation, 1)
 
 
 def kan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_spline: Sequence[Tensor], prelu_a: Sequence[Tensor],

@@ -153,6 +153,20 @@ CASES_1D = [
 ]
 
 
+# ---- 3-D shim of the B-spline layer (kan_layers.py:261-271): [B, C, D, H, W] inputs
+CASES_3D = [
+    C("bspline", "3d_tiny", 2, 3, 4, 6, 6, ndim=3, D=5),
+    C("bspline", "3d_s2g2_affine", 2, 4, 6, 8, 6, ndim=3, D=7, s=2, groups=2, act="silu", norm_kwargs={"affine": True}),
+    C("bspline", "3d_k1", 2, 5, 7, 4, 4, ndim=3, D=3, k=1, p=0),
+    C("bspline", "3d_d2p0_x2", 2, 3, 4, 7, 7, ndim=3, D=7, d=2, p=0, xs=2.0),
+    C("bspline", "3d_p2", 1, 2, 5, 4, 5, ndim=3, D=3, p=2, act="none"),
+    C("rbf", "3d_tiny", 2, 3, 4, 6, 6, ndim=3, D=5),
+    C("rbf", "3d_s2g2_p0", 2, 4, 6, 7, 6, ndim=3, D=6, s=2, groups=2, p=0, xs=2.0),
+    C("cheby", "3d_tiny", 2, 3, 4, 6, 6, ndim=3, D=5),
+    C("cheby", "3d_deg4_d2_affine", 2, 4, 6, 7, 7, ndim=3, D=6, degree=4, d=2, p=2, groups=2, norm_kwargs={"affine": True}),
+]
+
+
 # ---- ReLU-KAN (relu_kan_layers.py): trainable per-channel phases, perturbed so that channels differ; own seed range
 RELU_CASES = [
     C("relu", "tiny", 2, 3, 4, 8, 8),
@@ -213,6 +227,8 @@ def build_ref(c):
                 kw[key] = c[key]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
+        if c.get("ndim", 2) == 3:
+            return REF_LAYERS.KANConv3DLayer(c["C"], c["O"], **kw)
         return (KANConv1DLayer if one_d else KANConv2DLayer)(c["C"], c["O"], **kw)
     if c["kind"] == "rbf":
         for key in ("grid_size", "grid_range"):
@@ -220,9 +236,13 @@ def build_ref(c):
                 kw[key] = c[key]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
+        if c.get("ndim", 2) == 3:
+            return REF_LAYERS.FastKANConv3DLayer(c["C"], c["O"], **kw)
         return (FastKANConv1DLayer if one_d else FastKANConv2DLayer)(c["C"], c["O"], **kw)
     if "degree" in c:
         kw["degree"] = c["degree"]
+    if c.get("ndim", 2) == 3:
+        return REF_LAYERS.ChebyKANConv3DLayer(c["C"], c["O"], **kw)
     return (ChebyKANConv1DLayer if one_d else ChebyKANConv2DLayer)(c["C"], c["O"], **kw)
 
 
@@ -313,10 +333,14 @@ def run_case(idx, c):
                 det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
             elif p.dim() == 3 and c.get("ndim", 2) == 1:        # Conv1d weights [O, C, k]
                 det_fill(p, idx * 31 + j, (3.0 / (p.shape[1] * p.shape[2])) ** 0.5)
+            elif p.dim() == 5 and c.get("ndim", 2) == 3:        # Conv3d weights [O, C, kd, kh, kw]
+                det_fill(p, idx * 31 + j, (3.0 / (p.shape[1] * p.shape[2] * p.shape[3] * p.shape[4])) ** 0.5)
             elif p.dim() == 5:                                  # JacobiKAN poly_weights [G, O/G, C/G*(deg+1), k, k]
                 fan_in = p.shape[2] * p.shape[3] * p.shape[4]
                 det_fill(p, idx * 31 + j, (3.0 / fan_in) ** 0.5)
     shape = (c["B"], c["C"], c["W"]) if c.get("ndim", 2) == 1 else (c["B"], c["C"], c["H"], c["W"])
+    if c.get("ndim", 2) == 3:
+        shape = (c["B"], c["C"], c["D"], c["H"], c["W"])
     x = mk_input(shape, idx, c["xscale"]).requires_grad_(True)
 
     pre_ref = []
@@ -493,6 +517,12 @@ def gram_cases():
         print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 
 
+def cases_3d():
+    for i, c in enumerate(CASES_3D):
+        worst, sz = run_case(7200 + i, c)
+        print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 def mlp_cases():
     for i, c in enumerate(MLP_CASES):
         worst, sz = run_mlp_case(i, c)
@@ -563,6 +593,8 @@ def main():
         return relu_cases()
     if "--gram-only" in sys.argv:
         return gram_cases()
+    if "--3d-only" in sys.argv:
+        return cases_3d()
     total = 0
     for i, c in enumerate(CASES):
         worst, sz = run_case(i, c)
@@ -574,6 +606,7 @@ def main():
     cases_1d()
     relu_cases()
     gram_cases()
+    cases_3d()
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)

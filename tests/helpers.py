@@ -61,6 +61,9 @@ def build_layer(c):
         return (K.ReLUKANConv1DLayer if c.get("ndim", 2) == 1 else K.ReLUKANConv2DLayer)(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] in POLY:
         return getattr(K, POLY[c["kind"]])(c["C"], c["O"], **layer_kwargs(c))
+    if c.get("ndim", 2) == 3:
+        return {"bspline": K.KANConv3DLayer, "rbf": K.FastKANConv3DLayer, "cheby": K.ChebyKANConv3DLayer}[c["kind"]](
+            c["C"], c["O"], **layer_kwargs(c))
     if c.get("ndim", 2) == 1:
         cls = {"bspline": K.KANConv1DLayer, "rbf": K.FastKANConv1DLayer, "cheby": K.ChebyKANConv1DLayer}[c["kind"]]
         return cls(c["C"], c["O"], **layer_kwargs(c))

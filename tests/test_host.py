@@ -135,8 +135,13 @@ def test_1d_shims_surface():
     assert isinstance(f.dropout, nn.Dropout1d) and f.conv_spec().stride == (1, 2) and list(f.state_dict())[-1] == "rbf.grid"
     c = K.ChebyKANConv1DLayer(3, 4, 3, degree=4)
     assert c.arange.shape == (1, 1, 5, 1) and list(c.state_dict()) == ["arange", "poly_conv.0.weight"]
+    v = K.KANConv3DLayer(4, 6, 3, groups=2, padding=1, dropout=0.1)            # kan_layers.py:261-271
+    assert v.spline_conv[0].weight.shape == (3, 16, 3, 3, 3) and isinstance(v.layer_norm[0], nn.InstanceNorm3d) and v.ndim == 3
+    assert isinstance(v.dropout, nn.Dropout3d) and list(v.state_dict())[:2] == ["base_conv.0.weight", "base_conv.1.weight"]
+    assert K.FastKANConv3DLayer(4, 6, 3).spline_conv[0].weight.shape == (6, 32, 3, 3, 3)
+    assert K.ChebyKANConv3DLayer(4, 6, 3, degree=4).arange.shape == (1, 1, 5, 1, 1, 1)
     with pytest.raises(NotImplementedError):
-        K.KANConvNDLayer(nn.Conv3d, nn.InstanceNorm3d, 3, 4, 3, 3, ndim=3)
+        K.ReLUConvNDLayer(nn.Conv3d, nn.InstanceNorm3d, None, 3, 4, 3, ndim=3)  # 3-D: the three hot-path families only
     with pytest.raises(Exception):
         a(torch.zeros(2, 4, 8, 8))                                # a 1-D layer takes [B, C, L]
 

@@ -36,7 +36,7 @@ class _Params(nn.Module):
         if "sd.phase_low" in d:                                   # ReLU-KAN: per-channel phases, g / k from the case
             self.phase_low, self.phase_high = (nn.Parameter(torch.from_numpy(d["sd.phase_" + w])) for w in ("low", "high"))
             self.g, self.k = c.get("extra", {}).get("g", 5), c.get("extra", {}).get("k", 3)
-        norm_cls = NORMS[c.get("norm", "in")] if c.get("ndim", 2) == 2 else nn.InstanceNorm1d
+        norm_cls = {1: nn.InstanceNorm1d, 3: nn.InstanceNorm3d}.get(c.get("ndim", 2)) or NORMS[c.get("norm", "in")]
         nch = (c["C"] if c["kind"] == "rbf" else c["O"]) // G
         kw = {k: v for k, v in c.get("norm_kwargs", {}).items()}
         self.layer_norm = nn.ModuleList([norm_cls(nch, **kw) for _ in range(G)])

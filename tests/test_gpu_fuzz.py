@@ -188,3 +188,33 @@ def test_random_1d_vs_oracle(seed, gpu_lib):
             layer.phase_low.add_(0.05 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.05 * torch.randn_like(layer.phase_high))
     x = torch.randn(B, C, Lx) * (1.0 + (seed % 2))
     _check(layer, cfg, x, dict(kind=kind, C=C, O=O, G=G, H=1, W=Lx, k=k, s=s_, d=d, p=p, B=B))
+
+
+THREE_D = {"bspline": "KANConv3DLayer", "rbf": "FastKANConv3DLayer", "cheby": "ChebyKANConv3DLayer"}
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + int(__import__("os").environ.get("KAN_FUZZ_3D_N", "18"))))
+def test_random_3d_vs_oracle(seed, gpu_lib):
+    """The 3-D shims (one 2-D launch set per depth tap: kan_layers.py:261-271 and siblings) over random volumes, kernels,
+    strides, dilations, paddings and groups."""
+    r = random.Random(11000 + seed)
+    kind = list(THREE_D)[seed % len(THREE_D)]
+    G = r.choice([1, 1, 2])
+    C, O = r.choice([1, 2, 3, 6]) * G, r.choice([1, 4, 16, 64]) * G
+    k = r.choice([1, 3, 3])
+    s_, d = r.choice([1, 1, 2]), r.choice([1, 1, 2])
+    p = r.choice([0, 1, 2])
+    D, H, W = r.choice([1, 2, 3, 5, 8]), r.choice([3, 4, 6, 8]), r.choice([3, 4, 7, 8])
+
+    def out(n):
+        return (n + 2 * p - d * (k - 1) - 1) // s_ + 1
+    if min(out(D), out(H), out(W)) <= 0 or out(D) * out(H) * out(W) < 4:
+        p, s_ = d * (k - 1), 1                                    # non-empty output with >= 4 values per InstanceNorm volume
+        if out(D) * out(H) * out(W) < 4:
+            H, W = 4, 4
+    B = r.choice([1, 2, 5])
+    torch.manual_seed(seed)
+    layer = getattr(K, THREE_D[kind])(C, O, k, groups=G, stride=s_, dilation=d, padding=p)
+    cfg = _cfg(kind, C, O, k=k, s=s_, p=p, d=d, groups=G, degree=3, ndim=3, act="gelu" if kind == "bspline" else "silu")
+    x = torch.randn(B, C, D, H, W) * (1.0 + (seed % 2))
+    _check(layer, cfg, x, dict(kind=kind, C=C, O=O, G=G, D=D, H=H, W=W, k=k, s=s_, d=d, p=p, B=B))

@@ -124,8 +124,9 @@ def conv3d_stage(basis_kw, kernel_size, stride, padding, dilation, groups, x, xn
         z2 = z2.view(B, n, *z2.shape[1:]).permute(0, 2, 1, 3, 4)                      # [B, O, n, Ho, Wo]
         z2 = F.pad(z2, (0, 0, 0, 0, dos[0], Do - dos[0] - n))
         z = z2 if z is None else z + z2
-    if z is None:
-        raise L.KanConvError("no depth tap reaches the input (kernel entirely inside the depth padding)")
+    if z is None:                                                 # every tap of every output lies in the depth padding: all zeros
+        ho, wo = spec.out_hw(H, W)
+        z = x.new_zeros((B, w_basis[0].shape[0] * groups, Do, ho, wo))
     return z
 
 

@@ -69,6 +69,32 @@ def one_step(model, x, t, reducer=None):
     return loss
 
 
+def train_step_timing(model, x, t, steps, warmup):
+    """Auxiliary figure, N = 1 only: the same step followed by the fused AdamW update (generic_train.py:24: lr 1e-3,
+    weight_decay 1e-4).  `value` above stays the fwd+bwd metric of BASELINE.json / SURVEY.md 8(d); this shows what a
+    full training step costs.  Runs after the main measurement (it moves the parameters into the optimizer's flat block)."""
+    try:
+        from convkan_amd import FusedAdamW
+        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+
+        def step():
+            opt.zero_grad()
+            F.cross_entropy(model(x), t).backward()
+            opt.step()
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        return {"optimizer": "FusedAdamW(lr=1e-3, weight_decay=1e-4)", "ms_per_step": round(el / steps * 1e3, 3),
+                "images_per_sec": round(x.shape[0] * steps / el, 1), "steps": steps}
+    except Exception as e:                                # auxiliary: never take the headline measurement down with it
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def profiled_traffic(kernel: str):
     """HBM bytes per launch of a kernel family, from the committed PMC pass (profiles/r01_hbm_traffic.json); None if absent."""
     try:
@@ -225,6 +251,8 @@ def main():
                          "end_to_end_frac": round(ips * wl["gflop_per_image"] / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
                          "kernels": kernels},
         }
+        if world == 1 and args.workload == "kan_vgg11":
+            out["with_optimizer"] = train_step_timing(model, x, t, args.steps, max(3, args.warmup // 2))
         if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)

@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kan_vgg11")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary with-optimizer timing (clean kernel profiles)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=96)
@@ -251,7 +252,7 @@ def main():
                          "end_to_end_frac": round(ips * wl["gflop_per_image"] / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
                          "kernels": kernels},
         }
-        if world == 1 and args.workload == "kan_vgg11":
+        if world == 1 and args.workload == "kan_vgg11" and not args.no_aux:
             out["with_optimizer"] = train_step_timing(model, x, t, args.steps, max(3, args.warmup // 2))
         if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)

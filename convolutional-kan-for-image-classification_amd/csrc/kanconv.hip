@@ -181,13 +181,16 @@ __device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
     return wp_row(q, tap, c, p);
 }
 
-__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, float* __restrict__ wp, PackGeo q, int src_kind,
-                                              long long wp_gstride) {
+// One launch covers both sources: blocks x < nb_base transpose the base weights (src_kind 0), the rest the basis weights.
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src_base, const float* __restrict__ src_basis,
+                                              float* __restrict__ wp, PackGeo q, int nb_base, long long wp_gstride) {
     __shared__ float tile[32][33];
+    const int src_kind = (int)blockIdx.x < nb_base ? 0 : 1;           // block-uniform
+    const int bx = src_kind == 0 ? blockIdx.x : blockIdx.x - nb_base;
     const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;       // source row length
-    src += (size_t)blockIdx.z * q.O * J;                              // group blockIdx.z: stacked sources, back-to-back packed blocks
+    const float* src = (src_kind == 0 ? src_base : src_basis) + (size_t)blockIdx.z * q.O * J;     // group blockIdx.z: stacked sources
     wp += (size_t)blockIdx.z * wp_gstride;
-    const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    const int j0 = bx * 32, o0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -202,13 +205,15 @@ __global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src, flo
     }
 }
 
-__global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, float* __restrict__ dst, PackGeo q, int src_kind,
-                                                int n_slabs, long long slab_elems, long long dwp_gstride) {
+__global__ __launch_bounds__(256) void k_unpack(const float* __restrict__ dwp, float* __restrict__ dst_base, float* __restrict__ dst_basis,
+                                                PackGeo q, int nb_base, int n_slabs, long long slab_elems, long long dwp_gstride) {
     __shared__ float tile[32][33];
+    const int src_kind = (int)blockIdx.x < nb_base ? 0 : 1;           // block-uniform: base gradient first, then basis
+    const int bx = src_kind == 0 ? blockIdx.x : blockIdx.x - nb_base;
     const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;
     dwp += (size_t)blockIdx.z * dwp_gstride;
-    dst += (size_t)blockIdx.z * q.O * J;
-    const int j0 = blockIdx.x * 32, o0 = blockIdx.y * 32;
+    float* dst = (src_kind == 0 ? dst_base : dst_basis) + (size_t)blockIdx.z * q.O * J;
+    const int j0 = bx * 32, o0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -2208,12 +2213,9 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
             if (hipMemsetAsync(wp + off, 0, (size_t)pl.KC * pl.Opad * 4, st) != hipSuccess) return fail("memset failed");
         }
     }
-    if (hb) {
-        dim3 grid(ceil_div(g->C * T, 32), pl.Opad / 32, G);
-        hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, wp, q, 0, wp_gs);
-    }
-    dim3 grid(ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32, G);
-    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_basis, wp, q, 1, wp_gs);
+    const int nb_base = hb ? ceil_div(g->C * T, 32) : 0;
+    dim3 grid(nb_base + ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32, G);
+    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, w_basis, wp, q, nb_base, wp_gs);
     if (wd && dw_direct(g, b)) {
         if (hipMemcpyAsync(wd, wp, (size_t)pl.packed_weight_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("memcpy failed");
     } else if (wd) {
@@ -2240,12 +2242,9 @@ int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const Ka
                            pl.bwd_weight_slab_elems, pl.bwd_weight_slab_elems);
         n_slabs = 1;
     }
-    if (hb) {
-        dim3 grid(ceil_div(g->C * T, 32), ceil_div(g->O, 32), G);
-        hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, q, 0, n_slabs, pl.bwd_weight_slab_elems, dwp_gs);
-    }
-    dim3 grid(ceil_div(g->C * b->n_basis * T, 32), ceil_div(g->O, 32), G);
-    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_basis, q, 1, n_slabs, pl.bwd_weight_slab_elems, dwp_gs);
+    const int nb_base = hb ? ceil_div(g->C * T, 32) : 0;
+    dim3 grid(nb_base + ceil_div(g->C * b->n_basis * T, 32), ceil_div(g->O, 32), G);
+    hipLaunchKernelGGL(k_unpack, grid, dim3(256), 0, st, dwp, dw_base, dw_basis, q, nb_base, n_slabs, pl.bwd_weight_slab_elems, dwp_gs);
     return launch_ok("unpack");
 }
 

@@ -90,13 +90,18 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
         n = self._n_planes()
         return self._spec(kind=L.BASIS_POLY, n_basis=n, order=1, act=self._act_code, p0=0.0, p1=0.0, table=_table(self._coeffs(), n))
 
-    def forward(self, x):
+    def forward(self, x, pool: bool = False):
+        """`pool=True`: max_pool2d(layer(x), 2, 2) with the pooling inside the InstanceNorm+PReLU kernels (see KANConvNDLayer)."""
         spec = self.conv_spec()
         wb = [m.weight for m in self.base_conv]
         ws = [m.weight for m in self.poly_conv]
         prelus = [m.weight for m in self.prelus]
         if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
+            if pool and self.dropout is None:
+                ho, wo = spec.out_hw(x.shape[2], x.shape[3])
+                if ho % 2 == 0 and wo % 2 == 0:
+                    return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
             y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
         else:
             z = ops.kan_conv(spec, x, None, wb, ws)
@@ -104,7 +109,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
             y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
             y = self.dropout(y)
-        return y
+        return torch.nn.functional.max_pool2d(y, 2, 2) if pool else y
 
 
 # ------------------------------------------------------------------------------------------- Bessel

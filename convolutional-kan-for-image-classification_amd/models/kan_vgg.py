@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.conv_layers import KANConvNDLayer
+from ..layers.poly_layers import _RecurrenceKANConvNDLayer
 from ..layers.kan_conv import CONV_KAN_FACTORY
 from ..layers.mlp_layers import MLP_KAN_FACTORY
 
@@ -95,7 +96,7 @@ class VGGKAN(nn.Module):
         self.name = f"VGGKAN_{head}_{kan_conv.upper()}_{arch}"
 
     def forward_features(self, x):
-        """kan_vgg.py:142-146 `self.features(x)`, with one fusion: a B-spline KAN layer directly followed by the "M" entry
+        """kan_vgg.py:142-146 `self.features(x)`, with one fusion: a B-spline or recurrence-family KAN layer directly followed by the "M" entry
         (MaxPool2d(2, 2)) runs the pooling inside its InstanceNorm+PReLU kernels, so the un-pooled activation and its
         gradient never go through HBM.  Same values as the two modules in sequence (tests/test_gpu_models.py)."""
         mods = list(self.features)
@@ -103,7 +104,8 @@ class VGGKAN(nn.Module):
         while i < len(mods):
             m = mods[i]
             nxt = mods[i + 1] if i + 1 < len(mods) else None
-            if (self.fuse_pool and isinstance(m, KANConvNDLayer) and isinstance(nxt, nn.MaxPool2d) and _is_pool_2x2(nxt)):
+            if (self.fuse_pool and isinstance(m, (KANConvNDLayer, _RecurrenceKANConvNDLayer)) and getattr(m, "ndim", 2) == 2
+                    and isinstance(nxt, nn.MaxPool2d) and _is_pool_2x2(nxt)):
                 x = m(x, pool=True)
                 i += 2
             else:

@@ -310,3 +310,22 @@ def test_l1_wrapped_layer_runs_on_the_hip_path(gpu_lib):
     for n, p in w.module.named_parameters():
         pen = 0.1 * torch.sign(p.detach())
         assert relerr(p.grad, plain[n]) <= 1e-6 or relerr(p.grad, plain[n] + pen) <= 1e-6, n
+
+
+@pytest.mark.parametrize("fam", ["LucasKAN", "LaguerreKAN", "TaylorKAN"])
+def test_fused_maxpool_recurrence_families(fam, gpu_lib):
+    """The same fusion for the recurrence-family layers (their VGG variants hit it through VGGKAN.forward_features)."""
+    torch.manual_seed(1)
+    layer = K.CONV_KAN_FACTORY[fam](6, 128, 3).cuda()
+    x = torch.randn(5, 6, 8, 8, device="cuda")
+    go = torch.randn(5, 128, 4, 4, device="cuda")
+    outs = []
+    for fused in (True, False):
+        layer.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi, pool=True) if fused else F.max_pool2d(layer(xi), 2, 2)
+        y.backward(go)
+        outs.append((y.detach(), xi.grad, [p.grad.clone() for p in layer.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and relerr(outs[0][1], outs[1][1]) <= 2e-6
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert relerr(a, b) <= 2e-6

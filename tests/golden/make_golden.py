@@ -9,7 +9,9 @@ box).  For every case it
      (this is the oracle's pin; the script aborts on any mismatch), and
   4. freezes inputs, every state_dict tensor, outputs and all gradients into an .npz.
 
-Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            (everything)
+        ... make_golden.py --mlp-only | --poly-only [--kind=lucas] | --1d-only | --relu-only | --gram-only | --3d-only
+        (regenerate one fixture family; every family has its own seed range, so the others stay byte-identical)
 """
 import importlib
 import json

@@ -2,7 +2,7 @@
 """Headline benchmark: images/sec, forward + loss + backward, KAN-VGG11 (B-spline conv, grid 5, order 3, SiLU,
 InstanceNorm2d, Linear head), synthetic 3x32x32, batch 256 per GPU (BASELINE.json configs[2]; configs[3] for N>1).
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: this process starts N ranks itself, see launch_ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = zero grads, forward, CrossEntropy loss, backward (+ bucketed RCCL all-reduce of the gradients for N>1);
@@ -11,8 +11,13 @@ no optimizer step.  Rank 0 prints ONE JSON line.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
+
+# dmabuf IPC is the only mode the host driver supports: must be in the environment before the first HIP call of any rank
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch
 import torch.distributed as dist
@@ -95,15 +100,25 @@ def train_step_timing(model, x, t, steps, warmup):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
-def profiled_traffic(kernel: str):
-    """HBM bytes per launch of a kernel family, from the committed PMC pass (profiles/r01_hbm_traffic.json); None if absent."""
+def profiled(kernel: str):
+    """Committed counter evidence for a kernel family: HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) and the
+    matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES pass), newest round first; (None, None, None) if absent."""
+    fam = kernel.split("/")[0]
+    traffic = busy = src = None
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")) as f:
+                traffic = round(json.load(f)["kernels"][fam]["hbm_bytes_per_launch_corrected"])
+            src = f"profiles/{rnd}_hbm_traffic.json"
+            break
+        except (OSError, KeyError, ValueError):
+            continue
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as f:
-            doc = json.load(f)
-        fam = kernel.split("/")[0]
-        return round(doc["kernels"][fam]["hbm_bytes_per_launch_corrected"])
+        with open(os.path.join(ROOT, "profiles", "r02_mfma_busy.json")) as f:
+            busy = json.load(f)["kernels"][fam]
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return traffic, src, busy
 
 
 def host_cores() -> int:
@@ -125,33 +140,150 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(batch: int, iters: int):
-    """The oracle (CPU restatement of the reference op sequence, torch CPU ops) timed on this box's host cores."""
+def cpu_baseline(batch: int, iters: int, warmup: int):
+    """the oracle (CPU restatement of the reference op sequence kan_layers.py:197-247, torch CPU ops) on
+    this box's host cores -- batch 256, >= 3 warm-up + >= 10 timed iterations at every core this process may use, plus one short
+    run pinned to 8 threads for comparison with the build container's indicative 28-33 img/s."""
     from oracle.kan_oracle import OracleKANVGG
-    threads = host_cores()
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = OracleKANVGG().train()
     g = torch.Generator().manual_seed(1)
     x = torch.randn(batch, 3, 32, 32, generator=g)
     t = torch.randint(0, 10, (batch,), generator=g)
-    times = []
-    for i in range(iters + 1):
-        t0 = time.perf_counter()
-        m.zero_grad(set_to_none=True)
-        F.cross_entropy(m(x), t).backward()
-        times.append(time.perf_counter() - t0)
-    best = sum(times[1:]) / iters                      # first iteration is warm-up
-    return {"value": round(batch / best, 2), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle KAN-VGG11 fwd+loss+bwd, batch {batch}, mean of {iters} iters after 1 warm-up, torch {torch.__version__} CPU"}
+
+    def run(threads, n_warm, n_iter):
+        torch.set_num_threads(threads)
+        times = []
+        for _ in range(n_warm + n_iter):
+            t0 = time.perf_counter()
+            m.zero_grad(set_to_none=True)
+            F.cross_entropy(m(x), t).backward()
+            times.append(time.perf_counter() - t0)
+        timed = times[n_warm:]
+        return batch * len(timed) / sum(timed), min(timed), max(timed)
+
+    threads = host_cores()
+    ips, lo, hi = run(threads, warmup, iters)
+    out = {"value": round(ips, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"oracle KAN-VGG11 fwd+CE loss+bwd, batch {batch}, {iters} timed iterations after {warmup} warm-up "
+                     f"(iteration {lo:.2f}-{hi:.2f} s), torch {torch.__version__} CPU, os.cpu_count()={os.cpu_count()}"}
+    if threads != 8:
+        n8 = max(2, iters // 3)
+        ips8, lo8, hi8 = run(min(8, threads), 1, n8)
+        out["threads_8"] = {"value": round(ips8, 2), "unit": "images/sec", "cores": min(8, threads),
+                            "sample": f"same model and batch, torch.set_num_threads(8), {n8} timed iterations after 1 warm-up"}
+    return out
+
+
+# --------------------------------------------------------------------------------------------------- measurement
+def summarise(prof, elapsed_s, steps, batch, world, gflop_per_image):
+    """Per-kernel-family and per-layer roofline figures from the HIP-event samples of the timed steps."""
+    fam, lay = {}, {}
+    for smp in prof:
+        ms = smp.start.elapsed_time(smp.end)
+        f = fam.setdefault(smp.name, [0, 0.0, 0.0, 0.0])
+        f[0] += 1; f[1] += ms; f[2] += smp.flops; f[3] += smp.executed
+        l = lay.setdefault(smp.layer, {}).setdefault(smp.name.split("/")[0].replace("k_conv_", ""), [0, 0.0, 0.0, 0.0])
+        l[0] += 1; l[1] += ms; l[2] += smp.flops; l[3] += smp.executed
+    tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 2)
+    kernels = {n: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4), "tflops": tf(v[2], v[1]), "executed_tflops": tf(v[3], v[1]),
+                   "share_of_step": round(v[1] / (elapsed_s * 1e3), 3)} for n, v in fam.items()}
+    layers = {ln: {k: {"avg_ms": round(v[1] / v[0], 4), "tflops": tf(v[2], v[1]), "executed_tflops": tf(v[3], v[1])} for k, v in ks.items()}
+              for ln, ks in lay.items()}
+    dom = max(fam, key=lambda n: fam[n][1])
+    d = fam[dom]
+    all_t, all_f, all_x = (sum(v[i] for v in fam.values()) for i in (1, 2, 3))
+    ips = world * batch * steps / elapsed_s
+    traffic, traffic_src, busy = profiled(dom)
+    roof = {"bound": "mfma", "kernel": dom, "achieved": tf(d[2], d[1]), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(d[2] / (d[1] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "mfma_busy": busy,
+            "avg_launch_ms": kernels[dom]["avg_ms"], "flops_per_launch": round(d[2] / d[0] / 1e9, 3),
+            # work the matrix pipe really runs: position-major launches skip the (position, tap) products that multiply zero padding
+            "executed_flops_per_launch": round(d[3] / d[0] / 1e9, 3),
+            "executed_frac": round(d[3] / (d[1] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "all_conv_kernels_tflops": tf(all_f, all_t), "all_conv_kernels_executed_tflops": tf(all_x, all_t),
+            "conv_kernel_share_of_step": round(all_t / (elapsed_s * 1e3), 3),
+            # dense count per image (SURVEY.md 8(d): 3 x forward, includes the first layer's bwd-data although no launch computes it)
+            "end_to_end_frac": round(ips * gflop_per_image / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
+            # executed count: FLOPs of the launches that ran (no bwd-data of the first layer, no dead taps) / step time / peak
+            "end_to_end_executed_frac": round(all_x / steps / (elapsed_s / steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "kernels": kernels, "layers": layers}
+    return ips, roof
+
+
+def timed_steps(model, x, t, steps, warmup, reducer=None, barrier=None):
+    from convkan_amd import ops
+    barrier = barrier or torch.cuda.synchronize
+    for _ in range(warmup):
+        one_step(model, x, t, reducer)
+    barrier()
+    ops.PROFILE = []                                  # HIP events around every conv-kernel launch of the timed steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one_step(model, x, t, reducer)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    return elapsed, prof, loss
+
+
+def other_workload(name, device, steps, warmup):
+    """Short leg for BASELINE.json configs[1] / configs[4] (N = 1 only; not the recorded metric): same step definition."""
+    try:
+        wl = WORKLOADS[name]
+        model = build_model(device, name)
+        g = torch.Generator(device=device).manual_seed(1)
+        x = torch.randn(wl["batch"], *wl["shape"], device=device, generator=g)
+        t = torch.randint(0, 10, (wl["batch"],), device=device, generator=g)
+        elapsed, prof, _ = timed_steps(model, x, t, steps, warmup)
+        ips, roof = summarise(prof, elapsed, steps, wl["batch"], 1, wl["gflop_per_image"])
+        keep = ("kernel", "achieved", "frac", "executed_frac", "avg_launch_ms", "all_conv_kernels_tflops", "conv_kernel_share_of_step",
+                "end_to_end_frac", "end_to_end_executed_frac", "kernels")
+        out = {"workload": wl["desc"], "per_gpu_batch": wl["batch"], "steps": steps, "warmup": warmup,
+               "ms_per_step": round(elapsed / steps * 1e3, 3), "images_per_sec": round(ips, 1), "roofline": {k: roof[k] for k in keep}}
+        del model, x, t, prof
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:                                # auxiliary: never take the headline measurement down with it
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+# --------------------------------------------------------------------------------------------------- multi-rank launch
+def launch_ranks(n: int, argv, script: str = None, check_devices: bool = True):
+    """`python bench.py --gpus N` with N > 1 (or --spawn): start N fresh worker processes -- one per GPU, a
+    torch.distributed.run child -- relay rank 0's JSON line and exit with the child's code.  This parent never touches the GPU
+    (no HIP call, nothing re-executed): it decides from the arguments alone, before anything else runs."""
+    have = None
+    if check_devices:
+        try:
+            have = torch.cuda.device_count()          # device enumeration only; does not create a HIP context
+        except Exception:
+            pass
+    if have is not None and have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this node exposes {have} GPU(s)")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + [a for a in argv if a != "--spawn"]
+    print("[bench] launching", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=dict(os.environ, KAN_BENCH_LAUNCHED="1"), text=True)
+    line = None
+    for ln in proc.stdout:                             # rank 0 prints exactly one JSON line on stdout; anything else is noise
+        if ln.lstrip().startswith("{") and '"metric"' in ln:
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and line is not None:                   # a rank that died after rank 0 printed makes the whole run invalid
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+    sys.exit(rc)
 
 
 def main():
-    # stdout carries exactly ONE line (the JSON).  Native libraries print banners there (RCCL: "RCCL version : ..." at
-    # communicator creation), so fd 1 points at stderr until the result is ready.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -159,30 +291,40 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="images per GPU (default: the workload's)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kan_vgg11")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary with-optimizer timing (clean kernel profiles)")
-    ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary legs (with-optimizer timing, other workloads): clean kernel profiles")
+    ap.add_argument("--cpu-batch", type=int, default=256)
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-warmup", type=int, default=3)
     ap.add_argument("--bucket-mb", type=int, default=96)
     ap.add_argument("--force-dp", action="store_true", help="run the bucketed all-reduce path even with one rank (path rehearsal)")
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through the launcher even for --gpus 1")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if (args.gpus > 1 or args.spawn) and world_env is None:
+        launch_ranks(args.gpus, sys.argv[1:])           # does not return
+    # stdout carries exactly ONE line (the JSON).  Native libraries print banners there (RCCL: "RCCL version : ..." at
+    # communicator creation), so fd 1 points at stderr until the result is ready.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py directly (it launches its own ranks) or with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs a ROCm device"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dp
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)          # nccl == RCCL on ROCm
 
     import convkan_amd
-    from convkan_amd import ops
     convkan_amd.build_library()
 
     wl = WORKLOADS[args.workload]
@@ -192,8 +334,9 @@ def main():
     reducer = None
     if use_dist:
         from convkan_amd.parallel import BucketedGradReducer
-        for p in model.parameters():                               # identical replicas (same seed); make it explicit
-            dist.broadcast(p.data, 0)
+        with torch.no_grad():
+            for p in model.parameters():                           # identical replicas (same seed); make it explicit
+                dist.broadcast(p, 0)
         reducer = BucketedGradReducer(model.parameters(), bucket_bytes=args.bucket_mb << 20, always_reduce=args.force_dp)
     g = torch.Generator(device=device).manual_seed(1 + rank)
     x = torch.randn(args.batch, *wl["shape"], device=device, generator=g)
@@ -204,16 +347,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step(model, x, t, reducer)
-    barrier()
-    ops.PROFILE = []                                  # HIP events around every conv-kernel launch of the timed steps
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = one_step(model, x, t, reducer)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof, ops.PROFILE = ops.PROFILE, None
+    elapsed, prof, loss = timed_steps(model, x, t, args.steps, args.warmup, reducer, barrier)
     if rank == 0:
         print(f"[bench] {args.steps} steps in {elapsed:.3f}s on {world} GPU(s)", file=sys.stderr, flush=True)
     if use_dist:
@@ -222,19 +356,7 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        # ---- per-kernel roofline from the HIP events
-        fam = {}
-        for name, flops, e0, e1 in prof:
-            ms = e0.elapsed_time(e1)
-            f = fam.setdefault(name, [0, 0.0, 0.0])
-            f[0] += 1; f[1] += ms; f[2] += flops
-        kernels = {n: {"launches": v[0], "avg_ms": round(v[1] / v[0], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2),
-                       "share_of_step": round(v[1] / (elapsed * 1e3), 3)} for n, v in fam.items()}
-        dom = max(fam, key=lambda n: fam[n][1])
-        ach = fam[dom][2] / (fam[dom][1] * 1e-3) / 1e12
-        all_t = sum(v[1] for v in fam.values())
-        all_f = sum(v[2] for v in fam.values())
-        ips = world * args.batch * args.steps / elapsed
+        ips, roof = summarise(prof, elapsed, args.steps, args.batch, world, wl["gflop_per_image"])
         out = {
             "metric": wl["metric"],
             "value": round(ips, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,19 +365,24 @@ def main():
             "config": {"workload": wl["desc"], "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}" if world > 1 else "single",
                        "loss": round(float(loss.detach()), 6)},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": profiled_traffic(dom),
-                         "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes/launch)",
-                         "avg_launch_ms": kernels[dom]["avg_ms"], "flops_per_launch": round(fam[dom][2] / fam[dom][0] / 1e9, 3),
-                         "all_conv_kernels_tflops": round(all_f / (all_t * 1e-3) / 1e12, 2),
-                         "conv_kernel_share_of_step": round(all_t / (elapsed * 1e3), 3),
-                         "end_to_end_frac": round(ips * wl["gflop_per_image"] / 1e3 / world / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "kernels": kernels},
+            # ranks of the RCCL communicator the gradient all-reduce ran on (0: single process, no collective in the step)
+            "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "launcher": "bench.py -> torch.distributed.run" if os.environ.get("KAN_BENCH_LAUNCHED") else ("torch.distributed.run" if world_env else "none"),
+            "roofline": roof,
         }
-        if world == 1 and args.workload == "kan_vgg11" and not args.no_aux:
+        del prof
+        if reducer is not None:
+            out["allreduce"] = {"buckets": len(reducer.buckets), "bucket_mb": args.bucket_mb,
+                                "bytes_per_step": sum(b.flat.numel() * 4 for b in reducer.buckets), "op": "avg, side stream, reverse order"}
+        aux = world == 1 and not use_dist and args.workload == "kan_vgg11" and not args.no_aux
+        if aux:
             out["with_optimizer"] = train_step_timing(model, x, t, args.steps, max(3, args.warmup // 2))
+            del model, x, t
+            torch.cuda.empty_cache()
+            out["other_workloads"] = {"fastkan_layer": other_workload("fastkan_layer", device, 30, 10),
+                                      "cheby_alexnet": other_workload("cheby_alexnet", device, 10, 3)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters, args.cpu_warmup)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

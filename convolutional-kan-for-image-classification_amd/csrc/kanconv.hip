@@ -1583,8 +1583,8 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* __restrict__ z, int n_slabs, long long slab_elems,
-                                                      float* __restrict__ z_out, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* z, int n_slabs, long long slab_elems,     // z_out may alias z (slab 0)
+                                                      float* z_out, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ prelu_a,
                                                       float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                       int n_planes, int Cn, int HW, long long bstride, float eps, int prelu_span,
@@ -1804,8 +1804,7 @@ DevGeom dev_geom(const KanGeom* g) {
 enum { PM_FWD = 0, PM_BWD_DATA = 1, PM_BWD_WEIGHT = 2 };
 bool want_pix_major(const KanGeom* g, const KanBasis* b, int which) {
     const int plane = which == PM_BWD_DATA ? g->H * g->W : g->Ho * g->Wo;
-    int limit = which == PM_BWD_WEIGHT ? 16 : 4;
-    if (const char* e = getenv("KAN_PM_LIMIT")) limit = atoi(e);          // tuning knob (experiments only)
+    const int limit = which == PM_BWD_WEIGHT ? 16 : 4;
     return b->kind != KAN_BASIS_RBF && plane <= limit && g->kh * g->kw <= 32 && (g->ph > 0 || g->pw > 0) && g->B >= 16;
 }
 
@@ -1857,18 +1856,29 @@ int launch_ok(const char* what) {
 }
 
 int fast_variant(const KanBasis* b);
+// A/B switches for kernel experiments (NAME=0 turns a code path off).  The shipped library has none: it reads no
+// environment variable and keeps no mutable global state (include/kanconv.h).  Build with -DKAN_TUNING_KNOBS to get them.
+inline bool tuning_off(const char* name) {
+#ifdef KAN_TUNING_KNOBS
+    const char* e = getenv(name);
+    return e && atoi(e) == 0;
+#else
+    (void)name;
+    return false;
+#endif
+}
 // 256-output tiles (512 threads, 2 workgroups per CU): every expanded input value then feeds 256 outputs instead of 128,
 // which halves the staging work (basis evaluation + LDS writes: ~13 % of the forward kernel's time, measured by
 // ablation) per MFMA.  Offered where the compile-time basis specs exist and O is a multiple of 256.
 bool big_tiles(const KanBasis* b, const KanPlan& pl) {
-    static const int off = getenv("KAN_BIG") ? (atoi(getenv("KAN_BIG")) == 0) : 0;         // KAN_BIG=0: A/B switch (tuning only)
+    const bool off = tuning_off("KAN_BIG");
     const int f = fast_variant(b);
     return !off && pl.Opad % 256 == 0 && (f == 1 || f == 2 || f == 4 || f == 6);
 }
 // Halo forward kernel (k_conv_fwd_halo): 3x3 / stride 1 / pad 1 layers of the default B-spline specs whose 128-pixel
 // tiles are whole row blocks of one image or whole images (the KAN-VGG shapes 32x32, 16x16, 8x8, 4x4).
 bool halo_fwd(const KanGeom* g, const KanBasis* b) {
-    static const int off = getenv("KAN_HALO") ? (atoi(getenv("KAN_HALO")) == 0) : 0;       // KAN_HALO=0: A/B switch (tuning only)
+    const bool off = tuning_off("KAN_HALO");
     const int f = fast_variant(b);
     if (off || !(f == 1 || f == 2 || f == 5 || f == 6)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3
     if (b->kind == KAN_BASIS_POLY && b->order == 0) return false;          // order 0 = basis on a second, pre-normalised tensor (LegendreKAN): tap-major kernel
@@ -2000,7 +2010,7 @@ BwCfg bw_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
 
 // Depthwise groups (one input channel, <= 2 outputs per group, <= 9 taps): direct kernels instead of GEMM tiles.
 bool dw_direct(const KanGeom* g, const KanBasis* b) {
-    static const int off = getenv("KAN_DW") ? (atoi(getenv("KAN_DW")) == 0) : 0;           // KAN_DW=0: A/B switch (tuning only)
+    const bool off = tuning_off("KAN_DW");
     const int T = g->kh * g->kw, P = b->n_basis + (b->act != KAN_ACT_NONE);
     return !off && g->C == 1 && g->O <= 2 && T <= DW_T && T * P <= DW_MAX_TP;
 }

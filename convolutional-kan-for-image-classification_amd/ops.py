@@ -115,12 +115,22 @@ def _split_weights(spec: ConvSpec, weights: Sequence[torch.Tensor]):
 
 
 # --------------------------------------------------------------------------------------- optional kernel timing
-# bench.py sets PROFILE to a list; each conv-kernel launch then appends (kernel name, algorithmic FLOPs, start, end)
-# with HIP events recorded on the launch stream (torch's current stream is the stream handed to the C ABI).
+# bench.py sets PROFILE to a list; each conv-kernel launch then appends a KernelSample with HIP events recorded on the
+# launch stream (torch's current stream is the stream handed to the C ABI).
 PROFILE: Optional[list] = None
 
 
-def _launch(name: str, flops: float, t: torch.Tensor, fn) -> None:
+@dataclass
+class KernelSample:
+    name: str                 # kernel family + output-tile tag
+    flops: float              # dense algorithmic FLOPs of the launch
+    executed: float           # FLOPs the MFMA pipe really runs: structural zeros skipped by position-major launches removed
+    layer: str                # "C->O@HxW kKxK" of the launch
+    start: "torch.cuda.Event"
+    end: "torch.cuda.Event"
+
+
+def _launch(name: str, flops: float, t: torch.Tensor, fn, executed: Optional[float] = None, layer: str = "") -> None:
     if PROFILE is None:
         L.check(fn(), name)
         return
@@ -129,12 +139,40 @@ def _launch(name: str, flops: float, t: torch.Tensor, fn) -> None:
     e0.record(stream)
     L.check(fn(), name)
     e1.record(stream)
-    PROFILE.append((name, flops, e0, e1))
+    PROFILE.append(KernelSample(name, flops, flops if executed is None else executed, layer, e0, e1))
 
 
 def _conv_flops(geom, plan) -> float:
     """Dense algorithmic FLOPs of one conv-stage launch: 2*B*O*Ho*Wo*C*P*kh*kw per group."""
     return 2.0 * geom.B * geom.O * geom.Ho * geom.Wo * geom.C * plan.P * geom.kh * geom.kw * max(1, geom.groups)
+
+
+@lru_cache(maxsize=256)
+def _live_fraction(which: str, H: int, W: int, Ho: int, Wo: int, kh: int, kw: int, sh: int, sw: int, ph: int, pw: int, dh: int, dw: int) -> float:
+    """Share of the (position, tap) products that touch a real input pixel (the rest multiply zero padding).  The
+    position-major launches skip exactly those (kanconv.hip: live_taps_out / live_taps_in / live_positions_for_tap)."""
+    live = 0
+    for ho in range(Ho):
+        for wo in range(Wo):
+            for r in range(kh):
+                for t in range(kw):
+                    hi, wi = ho * sh - ph + r * dh, wo * sw - pw + t * dw
+                    live += 0 <= hi < H and 0 <= wi < W
+    return live / float(Ho * Wo * kh * kw)
+
+
+def _executed_flops(geom, plan, which: str) -> float:
+    """Dense count minus the dead (position, tap) products a position-major launch skips (plan.*_target > 0 marks one)."""
+    target = {"fwd": plan.fwd_target, "bwd_data": plan.bwd_data_target, "bwd_weight": plan.bwd_weight_target}[which]
+    dense = _conv_flops(geom, plan)
+    if target <= 0:
+        return dense
+    g = geom
+    return dense * _live_fraction(which, g.H, g.W, g.Ho, g.Wo, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw)
+
+
+def _layer_tag(geom) -> str:
+    return f"{geom.C * max(1, geom.groups)}->{geom.O * max(1, geom.groups)}@{geom.H}x{geom.W} k{geom.kh}x{geom.kw}"
 
 
 def _tile_tag(plan) -> str:
@@ -225,7 +263,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
     _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
             lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),
-                                     _ptr(x_pm), st))
+                                     _ptr(x_pm), st), _executed_flops(geom, plan, "fwd") if x_pm is not None else None, _layer_tag(geom))
     return z, (wd, x_pm), geom, basis, plan
 
 
@@ -234,19 +272,29 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
 # then writes the reference-layout gradient straight into the bucket and autograd adopts that view as .grad: the copy
 # "gradient -> bucket" (332 MB read + write per KAN-VGG11 step) disappears.  Single-group layers only (grouped layers
 # stack their per-group gradients in one tensor and keep the copy).
-GRAD_SINKS: "dict[int, tuple]" = {}                # id(Parameter) -> (weakref to it, bucket view of its shape)
+class GradSink:
+    """One registered sink: `view` is the bucket slice shaped like the Parameter.  `used` is set when a launch has written
+    through it and cleared by the reducer's finish(): a Parameter that feeds TWO graph nodes of one backward pass (a shared
+    layer) must not have both nodes write the same buffer -- autograd would then sum two aliases of the last gradient."""
+    __slots__ = ("ref", "view", "used")
+
+    def __init__(self, ref, view):
+        self.ref, self.view, self.used = ref, view, False
+
+
+GRAD_SINKS: "dict[int, GradSink]" = {}             # id(Parameter) -> its sink
 
 
 def _sink_for(wid, shape, device):
     ent = GRAD_SINKS.get(wid) if wid is not None else None
-    if ent is None:
+    if ent is None or ent.used:
         return None
-    ref, t = ent
-    p = ref()
+    p, t = ent.ref(), ent.view
     # only a FIRST gradient may be written in place: with .grad already set autograd accumulates, and the sink would
     # have overwritten the running sum
     if p is None or p.grad is not None or tuple(t.shape) != tuple(shape) or t.device != device or not t.is_contiguous():
         return None
+    ent.used = True
     return t
 
 
@@ -272,7 +320,8 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
         _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
                 lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
-                                                _ptr(dz_pm), st))
+                                                _ptr(dz_pm), st),
+                _executed_flops(geom, plan, "bwd_weight") if (x_pm is not None and dz_pm is not None) else None, _layer_tag(geom))
         sb = _sink_for(wids[0], (Og, Cg, kh, kw), x.device) if (wids and G == 1 and spec.has_base) else None
         ss = _sink_for(wids[1], (Og, Cg * spec.n_basis, kh, kw), x.device) if (wids and G == 1) else None
         dwb = (sb.unsqueeze(0) if sb is not None else
@@ -290,7 +339,8 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         dxns = torch.empty_like(dxs) if separate else None
         _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
                 lambda: lib.kan_conv_bwd_data(_ptr(dz), _ptr(x), _ptr(xs), _ptr(wd), _ptr(dxs), _ptr(dxns) if separate else C.c_void_p(0),
-                                              C.byref(geom), C.byref(basis), _ptr(dz_pm), st))
+                                              C.byref(geom), C.byref(basis), _ptr(dz_pm), st),
+                _executed_flops(geom, plan, "bwd_data") if dz_pm is not None else None, _layer_tag(geom))
         dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
     return dx, dxn, dw_base, dw_basis
 

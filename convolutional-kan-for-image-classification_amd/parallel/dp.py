@@ -12,6 +12,7 @@ distributed code at all, so there is no call pattern to mi
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import weakref
@@ -30,6 +31,7 @@ class _Bucket:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.pending = len(params)
+        self.seen = [False] * len(params)       # gradient of parameter i arrived this step
         self.work = None
 
 
@@ -38,6 +40,11 @@ class BucketedGradReducer:
 
     usage:   red = BucketedGradReducer(model.parameters()); ...; loss.backward(); red.finish()
     After ``finish()`` every ``p.grad`` holds the mean gradient over the process group.
+
+    Exactly ONE backward pass per ``finish()`` may run with the exchange armed.  Gradient accumulation over several
+    backward passes goes through ``no_sync()`` (as with torch DDP): passes inside it only accumulate into ``p.grad``, the
+    first pass outside it exchanges the accumulated sum.  A second armed pass before ``finish()`` raises -- the buckets
+    of the first would already be in flight.
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 96 << 20,
@@ -63,6 +70,7 @@ class BucketedGradReducer:
         # RCCL averages in the collective itself (ReduceOp.AVG); gloo (CPU tests) sums and the mean is taken afterwards
         self.avg_in_collective = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
         self.side = torch.cuda.Stream(device=plist[0].device) if self.cuda else None
+        self._armed = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in plist]
         # conv-KAN weights: let the weight-gradient kernels write into the bucket directly (ops.GRAD_SINKS); the hook then
         # finds .grad already in place and skips its copy
@@ -72,15 +80,32 @@ class BucketedGradReducer:
             for b in self.buckets:
                 for v, p in zip(b.views, b.params):
                     if p.dim() == 4:
-                        ops.GRAD_SINKS[id(p)] = (weakref.ref(p), v)
+                        ops.GRAD_SINKS[id(p)] = ops.GradSink(weakref.ref(p), v)
                         self._sinks.append(id(p))
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside only accumulate into ``p.grad`` (no bucket copy, no collective)."""
+        prev, self._armed = self._armed, False
+        try:
+            yield self
+        finally:
+            self._armed = prev
 
     # -- called by autograd right after p.grad has been written
     def _on_grad(self, p: torch.nn.Parameter):
+        if not self._armed:
+            return
         b, i = self._where[p]
+        if b.seen[i]:
+            raise RuntimeError("BucketedGradReducer: a second gradient arrived for a parameter before finish() -- the bucket of the "
+                               "first backward pass is already being all-reduced.  Wrap all but the last backward pass of an "
+                               "accumulation step in reducer.no_sync().")
+        b.seen[i] = True
         if p.grad.data_ptr() != b.views[i].data_ptr():      # (already there when the kernel wrote through a gradient sink)
             b.views[i].copy_(p.grad)
         b.pending -= 1
+        assert b.pending >= 0
         if b.pending == 0:
             self._launch(b)
 
@@ -113,6 +138,13 @@ class BucketedGradReducer:
                 if p.grad is not None:
                     p.grad = v
             b.pending = len(b.params)
+            b.seen = [False] * len(b.params)
+        if self._sinks:                                 # sinks are single-use per step (a parameter feeding two graph nodes)
+            from .. import ops
+            for k in self._sinks:
+                ent = ops.GRAD_SINKS.get(k)
+                if ent is not None:
+                    ent.used = False
 
     def remove(self):
         for h in self._hooks:

@@ -10,7 +10,7 @@ box).  For every case it
   4. freezes inputs, every state_dict tensor, outputs and all gradients into an .npz.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            (everything)
-        ... make_golden.py --mlp-only | --poly-only [--kind=lucas] | --1d-only | --relu-only | --gram-only | --3d-only
+        ... make_golden.py --mlp-only | --poly-only [--kind=lucas] | --1d-only | --relu-only | --gram-only | --3d-only | --model-only
         (regenerate one fixture family; every family has its own seed range, so the others stay byte-identical)
 """
 import importlib
@@ -567,48 +567,89 @@ def relu_margin(model, x):
     return min(seen) if seen else float("inf")
 
 
-def run_model(name, model, x, t):
-    model.eval()   # Dropout(0.5) in the heads must be inert for a deterministic fixture; InstanceNorm is unaffected
-    model_fill(model)
+def _to_fp64(model):
+    import copy
+    m = copy.deepcopy(model).double()
+    for mod in m.modules():                                     # `grid` is a plain attribute in the reference, .double() skips it
+        if isinstance(getattr(mod, "grid", None), torch.Tensor):
+            mod.grid = mod.grid.double()
+    return m
+
+
+def _model_pass(model, x, t):
+    """logits, loss, per-parameter gradient norm / abs-max / first 64 entries -- of one forward + CE + backward."""
+    model.zero_grad(set_to_none=True)
     logits = model(x)
     loss = F.cross_entropy(logits, t)
     loss.backward()
+    ps = [p for _, p in model.named_parameters()]
+    return {"logits": logits.detach().double().numpy().copy(), "loss": float(loss.detach()),
+            "grad_norm": np.array([float(p.grad.double().norm()) for p in ps]),
+            "grad_absmax": np.array([float(p.grad.abs().max()) for p in ps]),
+            "grad_head": np.stack([np.pad(p.grad.flatten()[:64].double().numpy(), (0, max(0, 64 - p.numel()))) for p in ps])}
+
+
+def _model_err(a, ref):
+    """The three model-level error figures of tests/test_gpu_models.py, of pass `a` against pass `ref`."""
+    return {"logits": float(np.abs(a["logits"] - ref["logits"]).max() / np.abs(ref["logits"]).max()),
+            "loss": abs(a["loss"] - ref["loss"]) / max(1.0, abs(ref["loss"])),
+            "grad_norm": float((np.abs(a["grad_norm"] - ref["grad_norm"]) / (ref["grad_norm"] + 1e-30)).max()),
+            "grad_slice": float((np.abs(a["grad_head"] - ref["grad_head"]).max(axis=1) / (ref["grad_absmax"] + 1e-30)).max())}
+
+
+def calibrate_model(model, x, t, base):
+    """How far the REFERENCE itself moves at model level (tests/test_gpu_models.py takes its tolerances from this):
+
+    * `fp32_vs_fp64`  -- the reference's fp32 pass against its own fp64 pass, for three fp32 execution variants whose only
+      difference is the summation order / kernel selection of the SAME ops: default threads, torch.set_num_threads(1), and
+      oneDNN disabled (torch.backends.mkldnn.flags(enabled=False): ATen's native conv instead of oneDNN's);
+    * `fp32_vs_fp32`  -- those variants against each other (a change of the reference's own summation order);
+    * `eps_response`  -- fp64 passes whose parameters and input were multiplied by (1 + u * 2^-24), u uniform in [-1, 1]: the
+      response of the exact model to ONE fp32 rounding of its inputs.  Any fp32 implementation commits such a rounding in
+      every layer, so its distance to the fp64 result is a small multiple of this figure however it orders its sums.
+    """
+    m64 = _to_fp64(model)
+    p64 = _model_pass(m64, x.double(), t)
+    variants = {"default": base}
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    variants["threads_1"] = _model_pass(model, x, t)
+    torch.set_num_threads(nthreads)
+    with torch.backends.mkldnn.flags(enabled=False):
+        variants["mkldnn_off"] = _model_pass(model, x, t)
+    cal = {"fp32_vs_fp64": {k: _model_err(v, p64) for k, v in variants.items()},
+           "fp32_vs_fp32": {f"{a}|{b}": _model_err(variants[a], variants[b]) for a, b in (("threads_1", "default"), ("mkldnn_off", "default"))}}
+    resp = []
+    gen = torch.Generator().manual_seed(2024)
+    for trial in range(4):
+        mp = _to_fp64(model)
+        with torch.no_grad():
+            for p in mp.parameters():
+                p.mul_(1.0 + (torch.rand(p.shape, generator=gen, dtype=torch.float64) * 2 - 1) * 2.0 ** -24)
+        xp = x.double() * (1.0 + (torch.rand(x.shape, generator=gen, dtype=torch.float64) * 2 - 1) * 2.0 ** -24)
+        resp.append(_model_err(_model_pass(mp, xp, t), p64))
+    cal["eps_response"] = {k: max(r[k] for r in resp) for k in resp[0]}
+    return p64, cal
+
+
+def run_model(name, model, x, t):
+    model.eval()   # Dropout(0.5) in the heads must be inert for a deterministic fixture; InstanceNorm is unaffected
+    model_fill(model)
+    base = _model_pass(model, x, t)
     names = [n for n, _ in model.named_parameters()]
-    gn = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
-    ga = np.array([float(p.grad.abs().max()) for _, p in model.named_parameters()])
-    # a few explicit gradient slices (first 64 entries of every parameter's grad)
-    gs = np.stack([np.pad(p.grad.flatten()[:64].numpy(), (0, max(0, 64 - p.numel()))) for _, p in model.named_parameters()])
-    np.savez(os.path.join(HERE, f"model_{name}.npz"), x=x.numpy(), t=t.numpy(), logits=logits.detach().numpy(),
-             loss=np.array(float(loss.detach())), grad_norm=gn, grad_absmax=ga, grad_head=gs,
-             names=np.frombuffer(json.dumps(names).encode(), dtype=np.uint8))
-    print(f"model {name}: loss {float(loss):.6f} params {sum(p.numel() for p in model.parameters())}")
+    p64, cal = calibrate_model(model, x, t, base)
+    np.savez(os.path.join(HERE, f"model_{name}.npz"), x=x.numpy(), t=t.numpy(), logits=base["logits"].astype(np.float32),
+             loss=np.array(base["loss"]), grad_norm=base["grad_norm"], grad_absmax=base["grad_absmax"],
+             grad_head=base["grad_head"].astype(np.float32),
+             names=np.frombuffer(json.dumps(names).encode(), dtype=np.uint8),
+             # fp64 pass of the reference model (same weights, same input) and the calibration of the model-level tolerances
+             logits64=p64["logits"], loss64=np.array(p64["loss"]), grad_norm64=p64["grad_norm"], grad_absmax64=p64["grad_absmax"],
+             grad_head64=p64["grad_head"], calib=np.frombuffer(json.dumps(cal).encode(), dtype=np.uint8))
+    print(f"model {name}: loss {base['loss']:.6f} params {sum(p.numel() for p in model.parameters())}")
+    print(json.dumps(cal, indent=1))
 
 
-def main():
-    if "--mlp-only" in sys.argv:                    # regenerate just the MLP KANLayer fixtures
-        return mlp_cases()
-    if "--poly-only" in sys.argv:                   # regenerate just the polynomial-family fixtures
-        return poly_cases()
-    if "--1d-only" in sys.argv:
-        return cases_1d()
-    if "--relu-only" in sys.argv:
-        return relu_cases()
-    if "--gram-only" in sys.argv:
-        return gram_cases()
-    if "--3d-only" in sys.argv:
-        return cases_3d()
-    total = 0
-    for i, c in enumerate(CASES):
-        worst, sz = run_case(i, c)
-        total += sz
-        print(f"{c['kind']:8s} {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
-    basis_probes()
-    mlp_cases()
-    poly_cases()
-    cases_1d()
-    relu_cases()
-    gram_cases()
-    cases_3d()
+def model_cases():
     kv, ka = import_ref_models()
     kv.cfgs["VGG11"] = O.VGG11_CFG
     torch.manual_seed(0)
@@ -624,6 +665,36 @@ def main():
             break
     print(f"cheby_alexnet input salt {salt}: min |ReLU input| = {margin:.2e}")
     run_model("cheby_alexnet", alex, xa, torch.tensor([5]))
+
+
+def main():
+    if "--mlp-only" in sys.argv:                    # regenerate just the MLP KANLayer fixtures
+        return mlp_cases()
+    if "--poly-only" in sys.argv:                   # regenerate just the polynomial-family fixtures
+        return poly_cases()
+    if "--1d-only" in sys.argv:
+        return cases_1d()
+    if "--relu-only" in sys.argv:
+        return relu_cases()
+    if "--gram-only" in sys.argv:
+        return gram_cases()
+    if "--3d-only" in sys.argv:
+        return cases_3d()
+    if "--model-only" in sys.argv:                  # the two model fixtures + their tolerance calibration
+        return model_cases()
+    total = 0
+    for i, c in enumerate(CASES):
+        worst, sz = run_case(i, c)
+        total += sz
+        print(f"{c['kind']:8s} {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+    basis_probes()
+    mlp_cases()
+    poly_cases()
+    cases_1d()
+    relu_cases()
+    gram_cases()
+    cases_3d()
+    model_cases()
     print(f"total layer fixtures: {total / 1e6:.2f} MB")
 
 

@@ -37,7 +37,26 @@ def _worker(rank, world, port, q):
         m.zero_grad(set_to_none=True)
         nn.functional.cross_entropy(m(x[rank * 4:(rank + 1) * 4]), t[rank * 4:(rank + 1) * 4]).backward()
         red.finish()
-    q.put((rank, [p.grad.clone() for p in m.parameters()], unused.grad))
+    grads = [p.grad.clone() for p in m.parameters()]
+    # gradient accumulation: the pass inside no_sync() only accumulates, the armed pass exchanges the sum
+    m.zero_grad(set_to_none=True)
+    xs, ts = x[rank * 4:(rank + 1) * 4], t[rank * 4:(rank + 1) * 4]
+    with red.no_sync():
+        nn.functional.cross_entropy(m(xs), ts).backward()
+    nn.functional.cross_entropy(m(xs), ts).backward()
+    red.finish()
+    acc = [p.grad.clone() for p in m.parameters()]
+    # a second ARMED pass before finish() must raise instead of reducing a bucket twice
+    m.zero_grad(set_to_none=True)
+    nn.functional.cross_entropy(m(xs), ts).backward()
+    try:
+        nn.functional.cross_entropy(m(xs), ts).backward()
+        raised = False
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    red.finish()
+    # numpy copies travel by value: torch tensors would be shared through file descriptors the parent may open only after this process is gone
+    q.put((rank, [g.numpy() for g in grads], unused.grad, [a.numpy() for a in acc], raised))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -52,9 +71,12 @@ def test_bucketed_allreduce_matches_single_process():
         p.start()
     got = dict()
     for _ in range(world):
-        r, grads, ug = q.get(timeout=150)
-        got[r] = grads
+        r, grads, ug, acc, raised = q.get(timeout=150)
+        got[r] = [torch.from_numpy(g) for g in grads]
         assert ug is None
+        assert raised, "a second armed backward pass before finish() did not raise"
+        for a, g in zip(acc, got[r]):
+            assert torch.allclose(torch.from_numpy(a), 2 * g, rtol=1e-5, atol=1e-7)
     for p in procs:
         p.join(30)
         assert p.exitcode == 0

@@ -13,12 +13,24 @@ from conftest import GOLDEN
 
 pytestmark = pytest.mark.gpu
 
-# Model-level fp32 tolerances.  Eight stacked layers with InstanceNorm over 4x4 and 2x2 planes amplify INDEPENDENT
-# rounding noise chaotically: per layer the HIP path is as accurate as the reference's own CPU fp32 path (both ~3e-7 of
-# max|y| against an fp64 run, tests/_acc_probe.py), yet at the logits the reference's fp32-vs-fp64 noise is 1.2e-5
-# and its grad-norm noise 8.5e-5 (tests/golden/make_golden.py calibration run), and two fp32 implementations with
-# different summation orders differ by an order of magnitude more than that.  DESIGN.md "Numerics" has the numbers.
-TOL_LOGITS, TOL_LOSS, TOL_GRAD_NORM, TOL_GRAD_SLICE = 1e-3, 1e-4, 5e-3, 2e-2
+# Model-level fp32 tolerances are CALIBRATED, not chosen: tests/golden/make_golden.py (--model-only) stores, next to the
+# reference's fp32 pass, its fp64 pass and how far the reference itself moves at model level
+#   * fp32 vs its own fp64 pass under three executions of the SAME ops (default, 1 thread, oneDNN off = another summation order),
+#   * those fp32 executions against each other, and
+#   * the exact (fp64) model's response to one fp32 rounding (2^-24 relative) of its parameters and input.
+# KAN-VGG11: with oneDNN off the reference moves by 1.7e-4 on the logits and 5.9e-4 on gradient norms against its own default
+# pass; ChebyKAN-AlexNet: 3.6e-3 / 1.0e-2 on gradient norms / slices against fp64 for EVERY variant (acos near the clamp).
+# A correct fp32 implementation with its own summation order therefore cannot be asked for less than ~that spread; the test
+# asserts  err <= max(stated SURVEY 8(c) tolerance, K_SPREAD x reference spread)  against BOTH the fp32 and the fp64 reference pass.
+K_SPREAD = 4.0
+STATED = {"logits": 1e-4, "loss": 1e-4, "grad_norm": 1e-3, "grad_slice": 1e-3}      # SURVEY.md section 8(c), model level
+
+
+def calibrated_tolerances(d):
+    cal = json.loads(bytes(d["calib"]).decode())
+    spread = {k: max([v[k] for v in cal["fp32_vs_fp64"].values()] + [v[k] for v in cal["fp32_vs_fp32"].values()] + [cal["eps_response"][k]])
+              for k in STATED}
+    return {k: max(STATED[k], K_SPREAD * spread[k]) for k in STATED}, spread
 
 
 def det_fill(t, salt, scale):
@@ -45,6 +57,7 @@ def run(name, model):
     d = np.load(os.path.join(GOLDEN, f"model_{name}.npz"))
     names = json.loads(bytes(d["names"]).decode())
     assert names == [n for n, _ in model.named_parameters()]
+    tol, spread = calibrated_tolerances(d)
     model_fill(model)                       # on CPU, exactly as the generator did
     model = model.cuda().eval()             # eval: head Dropout inert (the generator did the same)
     x = torch.from_numpy(d["x"]).cuda()
@@ -53,18 +66,22 @@ def run(name, model):
     loss = F.cross_entropy(logits, t)
     loss.backward()
     torch.cuda.synchronize()
-    ref = torch.from_numpy(d["logits"])
-    err = float((logits.detach().cpu() - ref).abs().max() / ref.abs().max())
+    got_logits = logits.detach().double().cpu().numpy()
     gn = np.array([float(p.grad.double().norm()) for _, p in model.named_parameters()])
-    rel = np.abs(gn - d["grad_norm"]) / (d["grad_norm"] + 1e-30)
-    head = np.stack([np.pad(p.grad.flatten()[:64].cpu().numpy(), (0, max(0, 64 - p.numel()))) for _, p in model.named_parameters()])
-    herr = np.abs(head - d["grad_head"]).max(axis=1) / (d["grad_absmax"] + 1e-30)
-    print(f"[{name}] logits err {err:.2e}  loss {float(loss):.6f} vs {float(d['loss']):.6f}  grad-norm rel err max {rel.max():.2e} "
-          f"({names[int(rel.argmax())]})  grad-slice err max {herr.max():.2e} ({names[int(herr.argmax())]})")
-    assert err <= TOL_LOGITS, f"logits err {err:.3e}"
-    assert abs(float(loss) - float(d["loss"])) <= TOL_LOSS * max(1.0, abs(float(d["loss"])))
-    assert rel.max() <= TOL_GRAD_NORM, f"grad-norm rel err {rel.max():.3e} at {names[int(rel.argmax())]}"
-    assert herr.max() <= TOL_GRAD_SLICE, f"grad slice err {herr.max():.3e} at {names[int(herr.argmax())]}"
+    head = np.stack([np.pad(p.grad.flatten()[:64].double().cpu().numpy(), (0, max(0, 64 - p.numel()))) for _, p in model.named_parameters()])
+    for tag, sfx in (("fp32 reference", ""), ("fp64 reference", "64")):
+        ref_logits = d["logits" + sfx].astype(np.float64)
+        err = float(np.abs(got_logits - ref_logits).max() / np.abs(ref_logits).max())
+        lerr = abs(float(loss) - float(d["loss" + sfx])) / max(1.0, abs(float(d["loss" + sfx])))
+        rel = np.abs(gn - d["grad_norm" + sfx]) / (d["grad_norm" + sfx] + 1e-30)
+        herr = np.abs(head - d["grad_head" + sfx]).max(axis=1) / (d["grad_absmax" + sfx] + 1e-30)
+        print(f"[{name} vs {tag}] logits {err:.2e} (tol {tol['logits']:.1e}, ref spread {spread['logits']:.1e})  loss {lerr:.2e}  "
+              f"grad-norm {rel.max():.2e} at {names[int(rel.argmax())]} (tol {tol['grad_norm']:.1e}, spread {spread['grad_norm']:.1e})  "
+              f"grad-slice {herr.max():.2e} at {names[int(herr.argmax())]} (tol {tol['grad_slice']:.1e}, spread {spread['grad_slice']:.1e})")
+        assert err <= tol["logits"], f"{tag}: logits err {err:.3e} > {tol['logits']:.3e}"
+        assert lerr <= tol["loss"], f"{tag}: loss err {lerr:.3e}"
+        assert rel.max() <= tol["grad_norm"], f"{tag}: grad-norm rel err {rel.max():.3e} at {names[int(rel.argmax())]}"
+        assert herr.max() <= tol["grad_slice"], f"{tag}: grad slice err {herr.max():.3e} at {names[int(herr.argmax())]}"
 
 
 def test_kan_vgg11(gpu_lib):
@@ -77,6 +94,48 @@ def test_cheby_alexnet(gpu_lib):
     from convkan_amd.models import alexnet_kan
     torch.manual_seed(0)
     run("cheby_alexnet", alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4))
+
+
+def test_kan_vgg11_bs256_vs_oracle(gpu_lib):
+    """The headline configuration itself (BASELINE.json configs[2]: KAN-VGG11, 256 x 3x32x32, train mode) against the CPU
+    oracle with the SAME weights: loss, logits and every parameter's gradient norm and direction (cosine).  Reference
+    composition: models/kan_vgg.py:178-188 over kan_layers.py:197-247.  Tolerances: the calibrated model-level ones of the
+    B = 2 fixture (same network; the batch mean over 256 samples only averages the per-sample noise down)."""
+    from convkan_amd.models import vggkan
+    from oracle.kan_oracle import OracleKANVGG
+    d = np.load(os.path.join(GOLDEN, "model_kan_vgg11.npz"))
+    tol, _ = calibrated_tolerances(d)
+    torch.manual_seed(0)
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear", dropout_linear=0.0)
+    o = OracleKANVGG()
+    o.classifier[0].p = 0.0
+    sd = m.state_dict()
+    osd = o.state_dict()
+    assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in osd.values()]
+    o.load_state_dict({k: v.clone() for k, v in zip(osd.keys(), sd.values())})      # same registration order, oracle-side names
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(256, 3, 32, 32, generator=g)
+    t = torch.randint(0, 10, (256,), generator=g)
+    o.train()
+    lo = o(x)
+    loss_o = F.cross_entropy(lo, t)
+    loss_o.backward()
+    m = m.cuda().train()
+    lg = m(x.cuda())
+    loss_g = F.cross_entropy(lg, t.cuda())
+    loss_g.backward()
+    torch.cuda.synchronize()
+    err = float((lg.detach().cpu() - lo.detach()).abs().max() / lo.detach().abs().max())
+    worst_n, worst_c = 0.0, 1.0
+    for (n, p), q in zip(m.named_parameters(), o.parameters()):
+        a, b = p.grad.detach().double().cpu().flatten(), q.grad.double().flatten()
+        worst_n = max(worst_n, abs(float(a.norm()) - float(b.norm())) / (float(b.norm()) + 1e-30))
+        worst_c = min(worst_c, float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)))
+    print(f"[kan_vgg11 bs256 vs oracle] logits {err:.2e}  loss {float(loss_g):.6f} vs {float(loss_o):.6f}  grad-norm {worst_n:.2e}  min cosine {worst_c:.8f}")
+    assert err <= tol["logits"]
+    assert abs(float(loss_g) - float(loss_o)) <= tol["loss"] * max(1.0, abs(float(loss_o)))
+    assert worst_n <= tol["grad_norm"]
+    assert worst_c >= 1.0 - 1e-5
 
 
 def test_training_step_is_bitwise_deterministic(gpu_lib):
@@ -132,7 +191,8 @@ def test_gradient_sinks_write_into_the_reducer_buckets(gpu_lib):
         hits = []
         hooks = [p.register_post_accumulate_grad_hook(lambda q: hits.append(q.grad.data_ptr() == views[id(q)].data_ptr())) for p in net[0].parameters()
                  if p.dim() == 4]
-        net(x).square().mean().backward()
+        with red.no_sync():                                                   # accumulation step: first pass only accumulates
+            net(x).square().mean().backward()
         assert hits and all(hits)                                             # single-group conv weights arrived in place
         net(x).square().mean().backward()                                     # second pass accumulates (no sink: .grad is set)
         red.finish()

@@ -54,9 +54,9 @@ def main():
         torch.cuda.synchronize()
         prof, ops.PROFILE = ops.PROFILE, None
         t = {}
-        for name, _, e0, e1 in prof:
-            key = name.split("/")[0].replace("k_conv_", "")
-            t[key] = t.get(key, 0.0) + e0.elapsed_time(e1) / a.iters
+        for smp in prof:
+            key = smp.name.split("/")[0].replace("k_conv_", "")
+            t[key] = t.get(key, 0.0) + smp.start.elapsed_time(smp.end) / a.iters
         t_all_f = timed(lambda: ops._conv_forward(spec, x, None, wb, ws), a.iters)
         t_all_b = timed(lambda: ops._conv_backward(spec, x, None, packed, dz, li != 0, False, True), a.iters)
         y = layer(x.requires_grad_(li != 0))

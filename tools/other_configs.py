@@ -39,6 +39,6 @@ print(f"config5 KAN-AlexNet ChebyKAN deg4 bs=128 3x224x224 fwd+bwd: {ms:.2f} ms 
 ops.PROFILE = []
 step5(); torch.cuda.synchronize()
 fam = {}
-for name, flops, e0, e1 in ops.PROFILE:
-    f = fam.setdefault(name, [0, 0.0, 0.0]); f[0] += 1; f[1] += e0.elapsed_time(e1); f[2] += flops
+for smp in ops.PROFILE:
+    f = fam.setdefault(smp.name, [0, 0.0, 0.0]); f[0] += 1; f[1] += smp.start.elapsed_time(smp.end); f[2] += smp.flops
 for n, v in fam.items(): print(f"   {n:28s} launches {v[0]:2d} total {v[1]:7.2f} ms  {v[2] / v[1] / 1e9:6.1f} TF")

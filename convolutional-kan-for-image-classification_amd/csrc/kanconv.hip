@@ -1575,8 +1575,21 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const float* __restrict__ s
 
 // ============================================================================ InstanceNorm + PReLU
 // G lanes cooperate on one (b, channel) plane; 256/G planes per workgroup.
+// Plane statistics are accumulated and combined in DOUBLE, as the reference's CPU path does (ATen's batch-norm CPU kernels
+// use at::acc_type<float, false> = double for the sums, the variance, k = dotp * invstd^2 / N and the final
+// (dy - mean(dy) - (x - mean) k) * invstd; kan_layers.py:242 -> F.instance_norm -> batch_norm).  It matters where the
+// backward cancels: the last KAN-VGG layer receives the gradient of a spatial mean, i.e. dy CONSTANT over each 2x2 plane, so
+// dy - mean(dy) is exactly zero and what survives is the small (x - mean) k term; with fp32 sums the bs-256 KAN-VGG11 weight
+// gradients were 1e-2 (L2) off the fp64 result where the reference's own fp32 path is 1e-4 off.  These kernels are
+// HBM-bound, the fp64 arithmetic is free.  mean / rstd are stored as fp32 (the reference's save_mean / save_invstd are too).
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
 #pragma unroll
     for (int off = G / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
@@ -1595,7 +1608,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* z, int n_slab
     const int b = act ? plane / Cn : 0, c = act ? plane - b * Cn : 0;
     const size_t base = (size_t)b * bstride + (size_t)c * HW;
     const bool need_sum = (n_slabs > 1) || (z_out != z);
-    float s = 0.f;
+    double s = 0.0;
     if (act) for (int i = sub; i < HW; i += G) {
         // split-K slabs: four independent partial sums keep four loads in flight (a 32-slab 2x2-plane layer spent its
         // whole time in this dependent chain); fixed order => deterministic
@@ -1609,13 +1622,13 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* z, int n_slab
         for (; sl < n_slabs; ++sl) v0 += zp[(size_t)sl * slab_elems];
         const float v = (v0 + v1) + (v2 + v3);
         if (need_sum) z_out[base + i] = v;
-        s += v;
+        s += (double)v;
     }
-    const float mu = group_sum<G>(s) / (float)HW;
-    float q = 0.f;
-    if (act) for (int i = sub; i < HW; i += G) { float d = z_out[base + i] - mu; q += d * d; }
-    const float var = group_sum<G>(q) / (float)HW;
-    const float rs = 1.0f / sqrtf(var + eps);
+    const double mu_d = group_sum<G>(s) / (double)HW;
+    double q = 0.0;
+    if (act) for (int i = sub; i < HW; i += G) { const double d = (double)z_out[base + i] - mu_d; q += d * d; }
+    const double var = group_sum<G>(q) / (double)HW;
+    const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps));
     if (!act) return;
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const bool has_p = prelu_a != nullptr;
@@ -1655,11 +1668,11 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
                                                       int n_planes, int Cn, int HW, long long bstride, int prelu_span,
                                                       const unsigned char* __restrict__ pidx, int W, FastDiv divW) {
     constexpr int EPL = 16;                         // elements per lane held in registers between the two passes
-    __shared__ float s_da[256 / G];
+    __shared__ double s_da[256 / G];
     const int tid = threadIdx.x, sub = tid % G;
     const bool has_p = prelu_a != nullptr;
     const bool in_regs = HW <= G * EPL;             // uniform
-    float sa_total = 0.f;                           // PReLU-slope gradient of every plane this workgroup visits
+    double sa_total = 0.0;                          // PReLU-slope gradient of every plane this workgroup visits
     // grid-stride over groups of 256/G planes: the grid is capped so that the single-address atomic on dprelu
     // (one per workgroup) stays cheap -- 16 k workgroups hammering one word cost 190 us
     for (int pg = blockIdx.x; pg * (256 / G) < n_planes; pg += gridDim.x) {
@@ -1670,8 +1683,8 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     const float mu = act ? mean_i[plane] : 0.f, rs = act ? rstd_i[plane] : 0.f;
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;
-    float rn[EPL], rd[EPL];                         // normalised value, d loss / d normalised value
-    float s1 = 0.f, s2 = 0.f, sa = 0.f, sg = 0.f, sb = 0.f;
+    float rc[EPL], rd[EPL];                         // centred value z - mean, d loss / d normalised value
+    double s1 = 0.0, s2 = 0.0, sa = 0.0, sg = 0.0, sb = 0.0;
     // upstream gradient of element i: plain, or through the fused MaxPool2d(2, 2) -- dy is then the dense pooled gradient and
     // only the element the forward marked in pidx receives it
     auto gy = [&](int i) -> float {
@@ -1680,49 +1693,52 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
         const size_t pq = (size_t)plane * (HW >> 2) + (size_t)((h >> 1) * (W >> 1) + (w >> 1));
         return pidx[pq] == (unsigned char)((h & 1) * 2 + (w & 1)) ? dy[pq] : 0.f;
     };
-    auto visit = [&](float zv, float g, float& nh, float& dnh) {
-        nh = (zv - mu) * rs;
+    // s1 = sum d,  s2 = sum d (z - mean)  with d = dL/d(normalised value): ATen's `sum` and `dotp`
+    auto visit = [&](float zv, float g, float& zc, float& dnh) {
+        zc = zv - mu;
+        const float nh = zc * rs;
         const float n = nh * ga + be;
         const bool neg = has_p && !(n > 0.f);
         const float dn = neg ? a * g : g;
-        if (neg) sa += n * g;
-        sb += dn; sg += dn * nh;
+        if (neg) sa += (double)n * (double)g;
+        sb += (double)dn; sg += (double)dn * (double)nh;
         dnh = dn * ga;
-        s1 += dnh; s2 += dnh * nh;
+        s1 += (double)dnh; s2 += (double)dnh * (double)zc;
     };
     if (in_regs) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = sub + e * G;
-            rn[e] = 0.f; rd[e] = 0.f;
-            if (act && i < HW) visit(z[base + i], gy(i), rn[e], rd[e]);
+            rc[e] = 0.f; rd[e] = 0.f;
+            if (act && i < HW) visit(z[base + i], gy(i), rc[e], rd[e]);
         }
     } else if (act) {
-        for (int i = sub; i < HW; i += G) { float nh, dnh; visit(z[base + i], gy(i), nh, dnh); }
+        for (int i = sub; i < HW; i += G) { float zc, dnh; visit(z[base + i], gy(i), zc, dnh); }
     }
     s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
     sa = group_sum<G>(sa); sg = group_sum<G>(sg); sb = group_sum<G>(sb);
-    const float m1 = s1 / (float)HW, m2 = s2 / (float)HW;
+    const double rs_d = (double)rs;
+    const double gm = s1 / (double)HW, kk = s2 * rs_d * rs_d / (double)HW;      // grad_mean and k of ATen's batch_norm_backward_cpu
     if (in_regs) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             const int i = sub + e * G;
-            if (act && i < HW) dz[base + i] = rs * (rd[e] - m1 - rn[e] * m2);
+            if (act && i < HW) dz[base + i] = (float)((((double)rd[e] - gm) - (double)rc[e] * kk) * rs_d);
         }
     } else if (act) {
         for (int i = sub; i < HW; i += G) {
-            float nh = (z[base + i] - mu) * rs;
-            float n = nh * ga + be;
-            float g = gy(i);
-            bool neg = has_p && !(n > 0.f);
-            float dnh = (neg ? a * g : g) * ga;
-            dz[base + i] = rs * (dnh - m1 - nh * m2);
+            const float zc = z[base + i] - mu;
+            const float n = zc * rs * ga + be;
+            const float g = gy(i);
+            const bool neg = has_p && !(n > 0.f);
+            const float dnh = (neg ? a * g : g) * ga;
+            dz[base + i] = (float)((((double)dnh - gm) - (double)zc * kk) * rs_d);
         }
     }
     if (act && sub == 0) {
-        if (dgamma) atomicAdd(&dgamma[c], sg);
-        if (dbeta) atomicAdd(&dbeta[c], sb);
-        if (prelu_span > 0) { if (dprelu) atomicAdd(&dprelu[c / prelu_span], sa); }      // per-group slopes (grouped layers)
+        if (dgamma) atomicAdd(&dgamma[c], (float)sg);
+        if (dbeta) atomicAdd(&dbeta[c], (float)sb);
+        if (prelu_span > 0) { if (dprelu) atomicAdd(&dprelu[c / prelu_span], (float)sa); }      // per-group slopes (grouped layers)
         else sa_total += sa;
     }
     }                                               // grid-stride loop
@@ -1730,9 +1746,9 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
         if (sub == 0) s_da[tid / G] = sa_total;
         __syncthreads();
         if (tid == 0) {
-            float t = 0.f;
+            double t = 0.0;
             for (int i = 0; i < 256 / G; ++i) t += s_da[i];
-            atomicAdd(dprelu, t);
+            atomicAdd(dprelu, (float)t);
         }
     }
 }

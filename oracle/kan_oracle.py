@@ -104,12 +104,16 @@ def kan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_spline: Sequence[Tensor], 
                *, knots: Tensor, spline_order: int, act: Optional[Callable[[Tensor], Tensor]],
                stride=1, padding=0, dilation=1, groups: int = 1,
                norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None,
-               pre_norm_out: Optional[list] = None) -> Tensor:
+               pre_norm_out: Optional[list] = None, prelu_gate: Optional[Tensor] = None) -> Tensor:
     """B-spline KAN conv layer (kan_layers.py:197-258).
 
     ``norm[g]`` is the output normalisation of group g; ``None`` means InstanceNorm2d with
     eps 1e-5, no affine (the reference's constructor default).  ``pre_norm_out`` (a list)
     receives the pre-normalisation sums, for tests of the conv stage alone.
+    ``prelu_gate`` (bool, shaped like the output; single-group layers): take the PReLU branch the caller names
+    instead of testing n > 0 -- parity tests use it to differentiate the SAME piecewise-linear branch as the
+    implementation under test where a normalised value sits within rounding noise of the kink (the value changes
+    by (1 - a)|n| ~ 1e-7 there, the gradient by O(1)).
     """
     def one(xg, g):
         a = xg if act is None else act(xg)
@@ -119,6 +123,9 @@ def kan_conv2d(x: Tensor, w_base: Sequence[Tensor], w_spline: Sequence[Tensor], 
         if pre_norm_out is not None:
             pre_norm_out.append(z)
         n = F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+        if prelu_gate is not None:
+            assert groups == 1
+            return torch.where(prelu_gate, n, prelu_a[g] * n)
         return F.prelu(n, prelu_a[g])
     return _per_group(x, groups, one)
 
@@ -375,9 +382,9 @@ class OracleKANConv2d(torch.nn.Module):
         self.knots = bspline_knots(grid_size, spline_order, grid_range)
         self.spline_order, self.padding, self.act = spline_order, padding, act
 
-    def forward(self, x):
+    def forward(self, x, prelu_gate=None):
         return kan_conv2d(x, [self.w_base], [self.w_spline], [self.prelu], knots=self.knots,
-                          spline_order=self.spline_order, act=self.act, padding=self.padding)
+                          spline_order=self.spline_order, act=self.act, padding=self.padding, prelu_gate=prelu_gate)
 
 
 class OracleKANVGG(torch.nn.Module):

@@ -96,46 +96,145 @@ def test_cheby_alexnet(gpu_lib):
     run("cheby_alexnet", alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4))
 
 
+def _capture(model, layer_type, xin, tt):
+    """One train-mode forward + CE + backward; per KAN layer (index in model.features): input x, output y, dL/dy, dL/dx."""
+    rec, hooks = {}, []
+
+    def pre(i):
+        def f(mod, args):
+            rec.setdefault(i, {})["x"] = args[0].detach()
+            if args[0].requires_grad:
+                args[0].register_hook(lambda g: rec[i].__setitem__("dx", g.detach()))
+        return f
+
+    def post(i):
+        def f(mod, args, out):
+            rec[i]["y"] = out.detach()
+            out.register_hook(lambda g: rec[i].__setitem__("dy", g.detach()))
+        return f
+    for i, f in enumerate(model.features):
+        if isinstance(f, layer_type):
+            hooks += [f.register_forward_pre_hook(pre(i)), f.register_forward_hook(post(i))]
+    model.train()
+    logits = model(xin)
+    loss = F.cross_entropy(logits, tt)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    return rec, logits.detach(), float(loss.detach())
+
+
 def test_kan_vgg11_bs256_vs_oracle(gpu_lib):
     """The headline configuration itself (BASELINE.json configs[2]: KAN-VGG11, 256 x 3x32x32, train mode) against the CPU
-    oracle with the SAME weights: loss, logits and every parameter's gradient norm and direction (cosine).  Reference
-    composition: models/kan_vgg.py:178-188 over kan_layers.py:197-247.  Tolerances: the calibrated model-level ones of the
-    B = 2 fixture (same network; the batch mean over 256 samples only averages the per-sample noise down)."""
+    oracle with the SAME weights (reference composition: models/kan_vgg.py:178-188 over kan_layers.py:197-247), run in fp64
+    (the yardstick) and in fp32 (what the reference arithmetic itself reproduces).  K = K_SPREAD throughout.
+
+    (a) logits / loss, and every layer's input activation: HIP-vs-fp64 <= max(1e-5, K x oracle-fp32-vs-fp64).
+    (b) every layer on the HIP model's OWN bs-256 input and output gradient: y, dx and the weight gradients against the fp64
+        oracle layer evaluated on exactly those tensors <= max(stated single-layer tolerance, K x what the fp32 oracle layer
+        achieves on them).  This is the parity statement proper: it holds to ~1e-6.  The oracle differentiates the PReLU
+        branch the HIP layer took (`prelu_gate`): among the 2 M normalised values of a layer a handful lie within rounding
+        noise of the kink, and ONE gate taken the other way moves a weight-gradient row by ~1e-2 of its magnitude (a row sums
+        4096 signed terms) with both sides correct.
+    (c) end-to-end parameter gradients.  Eight InstanceNorm layers over planes down to 2x2 followed by PReLU gates make the
+        gradient a DISCONTINUOUS function of the activations (measured on the fp64 model: activation noise 1e-6 moves the last
+        layer's weight gradient by 2e-5, noise 1e-5 by 2e-2), so the bound is the exact model's own response: the fp64 oracle
+        is re-run with Gaussian noise of the HIP path's measured per-layer activation error (L2) added to each layer input, and
+        the HIP gradients must lie within max(1e-3, K x that response) of the fp64 gradients."""
+    import copy
+    import convkan_amd as K
     from convkan_amd.models import vggkan
-    from oracle.kan_oracle import OracleKANVGG
-    d = np.load(os.path.join(GOLDEN, "model_kan_vgg11.npz"))
-    tol, _ = calibrated_tolerances(d)
+    from oracle.kan_oracle import OracleKANConv2d, OracleKANVGG
     torch.manual_seed(0)
     m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear", dropout_linear=0.0)
+    m.fuse_pool = False                                  # layer outputs at full size, so that (b) sees each layer's own dL/dy
     o = OracleKANVGG()
     o.classifier[0].p = 0.0
-    sd = m.state_dict()
-    osd = o.state_dict()
+    sd, osd = m.state_dict(), o.state_dict()
     assert [tuple(v.shape) for v in sd.values()] == [tuple(v.shape) for v in osd.values()]
     o.load_state_dict({k: v.clone() for k, v in zip(osd.keys(), sd.values())})      # same registration order, oracle-side names
+
+    def to64(mod):
+        mod = copy.deepcopy(mod).double()
+        for q in mod.modules():
+            if isinstance(getattr(q, "knots", None), torch.Tensor):
+                q.knots = q.knots.double()
+        return mod
+    o64 = to64(o)
     g = torch.Generator().manual_seed(1)
     x = torch.randn(256, 3, 32, 32, generator=g)
     t = torch.randint(0, 10, (256,), generator=g)
-    o.train()
-    lo = o(x)
-    loss_o = F.cross_entropy(lo, t)
-    loss_o.backward()
-    m = m.cuda().train()
-    lg = m(x.cuda())
-    loss_g = F.cross_entropy(lg, t.cuda())
-    loss_g.backward()
+    rec32, l32, loss32 = _capture(o, OracleKANConv2d, x, t)
+    g32 = [q.grad.double().flatten() for q in o.parameters()]
+    rec64, l64, loss64 = _capture(o64, OracleKANConv2d, x.double(), t)
+    g64 = [q.grad.flatten().clone() for q in o64.parameters()]
+    m = m.cuda()
+    rech, lh, lossh = _capture(m, K.KANConvNDLayer, x.cuda(), t.cuda())
     torch.cuda.synchronize()
-    err = float((lg.detach().cpu() - lo.detach()).abs().max() / lo.detach().abs().max())
-    worst_n, worst_c = 0.0, 1.0
-    for (n, p), q in zip(m.named_parameters(), o.parameters()):
-        a, b = p.grad.detach().double().cpu().flatten(), q.grad.double().flatten()
-        worst_n = max(worst_n, abs(float(a.norm()) - float(b.norm())) / (float(b.norm()) + 1e-30))
-        worst_c = min(worst_c, float(torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)))
-    print(f"[kan_vgg11 bs256 vs oracle] logits {err:.2e}  loss {float(loss_g):.6f} vs {float(loss_o):.6f}  grad-norm {worst_n:.2e}  min cosine {worst_c:.8f}")
-    assert err <= tol["logits"]
-    assert abs(float(loss_g) - float(loss_o)) <= tol["loss"] * max(1.0, abs(float(loss_o)))
-    assert worst_n <= tol["grad_norm"]
-    assert worst_c >= 1.0 - 1e-5
+    dist = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / (b.double().norm() + 1e-300))
+    dmax = lambda a, b: float((a.double().cpu() - b.double().cpu()).abs().max() / (b.double().abs().max() + 1e-300))
+    bad = []
+
+    # ---- (a) forward
+    e_hip, e_o32 = dist(lh, l64), dist(l32, l64)
+    print(f"[bs256 a] logits HIP-vs-fp64 {e_hip:.2e} (oracle fp32-vs-fp64 {e_o32:.2e});  loss HIP {lossh:.7f} fp32 {loss32:.7f} fp64 {loss64:.7f}")
+    assert e_hip <= max(1e-5, K_SPREAD * e_o32)
+    assert abs(lossh - loss64) <= max(STATED["loss"], K_SPREAD * abs(loss32 - loss64))
+    act_err = {}
+    for i in sorted(rech):
+        act_err[i] = dist(rech[i]["x"], rec64[i]["x"])
+        eo = dist(rec32[i]["x"], rec64[i]["x"])
+        print(f"[bs256 a] features.{i} input: HIP-vs-fp64 {act_err[i]:.2e}  oracle fp32-vs-fp64 {eo:.2e}")
+        if act_err[i] > max(1e-5, K_SPREAD * eo):
+            bad.append(("activation", i, act_err[i], eo))
+
+    # ---- (b) each layer on the HIP model's own input / output gradient
+    stated = {"y": 1e-5, "dx": 1e-5, "w_base": 5e-5, "w_spline": 5e-5, "prelu": 5e-5}
+    for i in sorted(rech):
+        fh = m.features[i]
+        got = {"y": rech[i]["y"], "dx": rech[i].get("dx"), "w_base": fh.base_conv[0].weight.grad, "w_spline": fh.spline_conv[0].weight.grad,
+               "prelu": fh.prelus[0].weight.grad}
+        ref = {}
+        for tag, lay, dt in (("f64", copy.deepcopy(o64.features[i]), torch.float64), ("f32", copy.deepcopy(o.features[i]), torch.float32)):
+            lay.zero_grad(set_to_none=True)
+            xi = rech[i]["x"].to(dt).cpu().requires_grad_(True)
+            yo = lay(xi, prelu_gate=(rech[i]["y"] > 0).cpu())
+            yo.backward(rech[i]["dy"].to(dt).cpu())
+            ref[tag] = {"y": yo.detach(), "dx": xi.grad, **{n: q.grad for n, q in lay.named_parameters()}}
+        line = f"[bs256 b] features.{i} on its own inputs:"
+        for k in got:
+            if got[k] is None:
+                continue
+            eh, eo = dmax(got[k], ref["f64"][k]), dmax(ref["f32"][k], ref["f64"][k])
+            line += f"  {k} {eh:.1e} ({eo:.1e})"
+            if eh > max(stated[k], K_SPREAD * eo):
+                bad.append(("own-input", i, k, eh, eo))
+        print(line + "   [HIP-vs-fp64 (oracle fp32-vs-fp64), max-normalised]")
+
+    # ---- (c) end-to-end gradients against the exact model's response to activation noise of the measured size
+    gen = torch.Generator().manual_seed(7)
+    hooks = []
+    for i, f in enumerate(o64.features):
+        if isinstance(f, OracleKANConv2d) and act_err.get(i, 0.0) > 0.0:
+            def noisy(mod, args, i=i):
+                a = args[0]
+                return (a + act_err[i] * a.pow(2).mean().sqrt() * torch.randn(a.shape, generator=gen, dtype=a.dtype),)
+            hooks.append(f.register_forward_pre_hook(noisy))
+    o64.zero_grad(set_to_none=True)
+    F.cross_entropy(o64(x.double()), t).backward()
+    for h in hooks:
+        h.remove()
+    gn = [q.grad.flatten() for q in o64.parameters()]
+    rows = [(n, dist(p.grad.flatten(), a64), dist(a32, a64), dist(an, a64), float(a64.norm()))
+            for (n, p), a32, a64, an in zip(m.named_parameters(), g32, g64, gn)]
+    # the eight PReLU slopes are single numbers, each a sum of millions of signed terms: their individual responses scatter
+    # by orders of magnitude from one noise draw to the next, so they share one bound (the largest response among them)
+    slope_bound = max(max(eo, er) for n, _, eo, er, _ in rows if "prelus" in n)
+    for n, eh, eo, er, norm in rows:
+        print(f"[bs256 c] {n:34s} |g| {norm:.3e}  HIP-vs-fp64 {eh:.2e}  oracle fp32-vs-fp64 {eo:.2e}  fp64 under HIP-sized activation noise {er:.2e}")
+        if eh > max(STATED["grad_norm"], K_SPREAD * (slope_bound if "prelus" in n else max(eo, er))):
+            bad.append(("gradient", n, eh, eo, er))
+    assert not bad, bad
 
 
 def test_training_step_is_bitwise_deterministic(gpu_lib):

@@ -1,4 +1,5 @@
-"""KAN-AlexNet caller (counterpart of the reference's models/kan_alexnet.py:10-313), plain FC head only."""
+"""KAN-AlexNet caller (counterpart of the reference's models/kan_alexnet.py:10-313): plain FC head ('Linear' / 'AlexNet') or the
+reference's 'KAN' head -- two Linear+ReLU stages and a B-spline MLP KAN as the last stage (`kan_fc3`, kan_alexnet.py:151-167,184-199)."""
 from functools import partial
 from inspect import signature
 from typing import Any, Callable, List, Optional
@@ -7,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from ..layers.kan_conv import CONV_KAN_FACTORY
+from ..layers.mlp_layers import MLP_KAN_FACTORY
 
 
 class AlexNetKAN(nn.Module):
@@ -15,10 +17,13 @@ class AlexNetKAN(nn.Module):
                  base_activation: Optional[Callable[..., nn.Module]] = nn.SiLU, grid_range: List = [-1, 1],
                  degree: Optional[int] = 3, l1_decay: float = 0.0, affine: bool = True,
                  kan_norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, classifier_dropout: Optional[float] = None,
-                 conv_dropout: float = 0.0, **kwargs: Any) -> None:
+                 conv_dropout: float = 0.0, kan_classifier: Optional[str] = "KAN", classifier_spline_order: Optional[int] = None,
+                 classifier_grid_size: Optional[int] = None, classifier_base_activation: Optional[Callable[..., nn.Module]] = None,
+                 classifier_grid_range: Optional[List] = None, classifier_l1_decay: Optional[float] = None,
+                 classifier_degree: Optional[int] = None, **kwargs: Any) -> None:
         super().__init__()
-        if classifier_type not in ("Linear", "AlexNet"):
-            raise NotImplementedError("KAN MLP heads are outside the accelerated path (classifier_type 'Linear' or 'AlexNet')")
+        if classifier_type in ("KAN", "AlexNetKAN") and (kan_classifier or "KAN") not in MLP_KAN_FACTORY:
+            raise NotImplementedError(f"kan_classifier={kan_classifier!r}: only the B-spline MLP KAN head is built ({list(MLP_KAN_FACTORY)})")
         if kan_conv not in CONV_KAN_FACTORY:
             raise ValueError(f"kan_conv={kan_conv!r} is not on the accelerated path: {list(CONV_KAN_FACTORY)}")
         make = CONV_KAN_FACTORY[kan_conv]
@@ -38,13 +43,24 @@ class AlexNetKAN(nn.Module):
         self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
         hid = 4096 if arch == "default" else 1024
         p = dropout if classifier_dropout is None else classifier_dropout
+        if classifier_type == "KAN":
+            # kan_alexnet.py:151-167: the head's KAN inherits the conv stage's spline settings unless overridden, takes the
+            # classifier dropout, and is filtered by the factory's signature; only the LAST stage is a KAN (184-199)
+            pick = lambda v, d: d if v is None else v
+            offered = dict(dropout=p, spline_order=pick(classifier_spline_order, spline_order), grid_size=pick(classifier_grid_size, grid_size),
+                           base_activation=pick(classifier_base_activation, base_activation), grid_range=pick(classifier_grid_range, grid_range),
+                           l1_decay=pick(classifier_l1_decay, l1_decay), degree=pick(classifier_degree, degree), first_dropout=False)
+            make_head = MLP_KAN_FACTORY[kan_classifier or "KAN"]
+            last = ("kan_fc3", make_head(layers_hidden=[hid, num_classes], **{k: v for k, v in offered.items() if k in signature(make_head).parameters}))
+        else:                                                     # 'Linear', 'AlexNet' and any other name: the plain head (168-183, 200-206)
+            last = ("fc3", nn.Linear(hid, num_classes))
         self.classifier = nn.Sequential()
         for name, mod in (("head_dropout1", nn.Dropout(p=p)), ("fc1", nn.Linear(256 * 6 * 6, hid)), ("relu1", nn.ReLU(True)),
-                          ("head_dropout2", nn.Dropout(p=p)), ("fc2", nn.Linear(hid, hid)), ("relu2", nn.ReLU(True)),
-                          ("fc3", nn.Linear(hid, num_classes))):
+                          ("head_dropout2", nn.Dropout(p=p)), ("fc2", nn.Linear(hid, hid)), ("relu2", nn.ReLU(True)), last):
             self.classifier.add_module(name, mod)
         self._initialize_weights()
-        self.name = f"AlexNet_{classifier_type}_{kan_conv.upper()}"
+        head = classifier_type + (f"_{(kan_classifier or 'KAN').upper()}" if classifier_type in ("KAN", "AlexNetKAN") else "")
+        self.name = f"AlexNet_{head}_{kan_conv.upper()}"
 
     def _initialize_weights(self) -> None:
         # kan_alexnet.py:236-250: every nn.Conv2d (including the KAN layers' weight holders) is re-initialised
@@ -69,6 +85,5 @@ def alexnet_kan(num_classes: int = 1000, input_channels: int = 3, dropout: float
                 conv_type: str = "kanconv", kan_conv: Optional[str] = "KAN", classifier_type: str = "Linear", **kwargs: Any) -> AlexNetKAN:
     if conv_type != "kanconv":
         raise NotImplementedError("only conv_type='kanconv' is on the accelerated path")
-    kwargs.pop("kan_classifier", None)
     return AlexNetKAN(num_classes=num_classes, dropout=dropout, input_channels=input_channels, arch=arch,
                       kan_conv=kan_conv or "KAN", classifier_type=classifier_type, **kwargs)

@@ -247,6 +247,16 @@ def test_models_build_with_reference_parameter_names():
     assert [n for n, _ in m.named_parameters()] == names and sum(p.numel() for p in m.parameters()) == 82964690
     a = alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4, arch="small")
     assert a.features[0].kernel_size == 5 and a.features[0].layer_norm[0].affine
+    # the reference's 'KAN' head (kan_alexnet.py:184-199): two Linear+ReLU stages, the last stage a B-spline MLP KAN `kan_fc3`;
+    # names / shapes as the reference builds them (checked against the imported reference when this head was added)
+    k = alexnet_kan(num_classes=10, kan_conv="KAN", classifier_type="KAN", arch="small", grid_size=4)
+    assert k.name == "AlexNet_KAN_KAN_KAN"
+    sd = {n: tuple(v.shape) for n, v in k.state_dict().items() if "kan_fc3" in n}
+    assert sd == {"classifier.kan_fc3.layers.0.base_weight": (10, 1024), "classifier.kan_fc3.layers.0.spline_weight": (10, 1024, 7),
+                  "classifier.kan_fc3.layers.0.layer_norm.weight": (10,), "classifier.kan_fc3.layers.0.layer_norm.bias": (10,),
+                  "classifier.kan_fc3.layers.0.prelu.weight": (1,)}
+    assert "classifier.fc3.weight" not in k.state_dict() and "classifier.fc2.weight" in k.state_dict()
+    assert alexnet_kan(num_classes=10, classifier_type="AlexNetKAN", arch="small").name == "AlexNet_AlexNetKAN_KAN_KAN"     # plain head, as the reference
 
 
 def test_l1_l2_wrapper_hook_semantics():

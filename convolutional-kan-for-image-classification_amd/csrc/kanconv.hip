@@ -162,7 +162,7 @@ __device__ __forceinline__ int mfma_row(int reg, int lane) { return (reg & 3) + 
 // divT / divNb / divIPC / divP: magic numbers for the per-element index divisions below.  With plain `/` the three layout
 // kernels spent ~100 VALU instructions per element on integer division and were ALU-bound, not HBM-bound (0.81 ms of a
 // 17.4 ms KAN-VGG11 step for 1 GB of traffic).
-struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair; FastDiv divT, divNb, divIPC, divP; };
+struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair, cmajor; FastDiv divT, divNb, divIPC, divP; };
 
 // Row of (tap, channel c, plane p) in the forward layout.  pair == 0: tap-major items as described above.  pair == 1 (the
 // halo forward kernel, P = 9, C even): a step of KC = 18 rows is one tap of a channel PAIR, row 2p + (c & 1), steps
@@ -170,6 +170,7 @@ struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair; FastDiv divT, divN
 // distance apart in the halo tile.
 __device__ __forceinline__ int wp_row(const PackGeo& q, int tap, int c, int p) {
     if (q.pair) return ((c >> 1) * q.T + tap) * q.KC + 2 * p + (c & 1);
+    if (q.cmajor) return (c * q.T + tap) * q.P + p;   // flat channel-major order of the halo weight-gradient kernel
     const int item = tap * q.C + c;                   // tap-major: all channels of a tap are contiguous in the depth axis
     const int chunk = fastdiv(item, q.divIPC);
     return chunk * q.KC + (item - chunk * q.IPC) * q.P + p;
@@ -1414,6 +1415,192 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         }
 }
 
+// ============================================================================ backward weight, halo variant
+// The tap-major kernel above expands every input value once per tap it is used under and once per row tile, and stages dz
+// through registers: 2.2 non-MFMA vector instructions per MFMA, and on gfx950 the fp32 MFMA shares the vector ALU.  Here
+//   * rows are CHANNEL-major, row = (c*T + tap)*P + p, so a 128-row tile is 1.6 channels x all nine taps: the workgroup
+//     expands the inputs of a BAND (R output rows of one image, 64 pixels = 4 MFMA steps) once per touched channel (<= 3)
+//     into a zero-bordered halo tile sH[channel][plane][cell]; the nine taps of a row read the A operand through a
+//     lane-constant shifted address, the pixel of a k-pair is an immediate offset (as k_conv_fwd_halo does for B);
+//   * dz never passes through registers: 16 pixels x 128 outputs per step arrive by LDS-DMA (buffer_load ... lds, 4 bytes
+//     per lane, 16 lanes = one 64-byte line of one output row), the per-step part of the address in a scalar register.
+//     LDS-DMA places lane i at base + 4 i, so rows cannot be padded; the row [o][16 px] is XOR-swizzled instead
+//     (word = px ^ ((o >> 1) & 15), chosen by the SOURCE address of each lane), which makes the B-operand reads of 32
+//     consecutive outputs at one pixel hit 32 distinct banks.  The swizzle is not additive, so a lane keeps its eight
+//     k-pair addresses in registers.
+// Per step and wave: 32 MFMA, 32 ds_read_b32, 8 DMA instructions, ~0.3 expansions -- about 0.4 vector instructions per
+// MFMA.  The weight gradient comes out in the channel-major flat order; kan_unpack_wgrad knows (halo_bwd_weight()).
+#define LDS_READ4W(r0, r1, r2, r3, a0, a1, b, oA, oB0, oB1)                                                              \
+    asm volatile("ds_read_b32 %0, %4 offset:%7\n\tds_read_b32 %1, %5 offset:%7\n\tds_read_b32 %2, %6 offset:%8\n\tds_read_b32 %3, %6 offset:%9" \
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a0), "v"(a1), "v"(b), "n"(oA), "n"(oB0), "n"(oB1) : "memory")
+
+template <int FAST, int W, int R>
+__global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
+    const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dwp, DevGeom g, DevBasis bs, int Krows, int Opad,
+    int n_bands, int bands_per_split, long long slab_elems, unsigned x_bytes, unsigned dz_bytes, int tiles_o) {
+    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : KAN_BASIS_BSPLINE;
+    constexpr int P = fast_planes(FAST), T = 9, PT = P * T;
+    constexpr int TR = 128, TO = 128, NT = 256, KPX = 16;
+    constexpr int HWc = W + 2, CELLS = (R + 2) * HWc;
+    constexpr int PS = W == 16 ? CELLS + 1 : W == 8 ? CELLS + 3 : CELLS + 1;     // plane stride: 2-way conflicts at worst on the A reads (brute-forced)
+    constexpr int NCH = (TR + PT - 2) / PT + 1;              // channels a 128-row tile can touch
+    constexpr int HB = NCH * P * PS;                         // floats per halo buffer
+    constexpr int BP = R * W, SPB = BP / KPX;                // pixels / MFMA steps per band
+    constexpr int ZB = KPX * TO;                             // floats per dz buffer
+    constexpr int NU = NCH * (R + 2) * W;                    // expansions per band (halo rows included, halo columns are borders)
+    constexpr int SLOTS = (NU + NT - 1) / NT;
+    static_assert(BP % KPX == 0 && SPB % 2 == 0 && SPB >= SLOTS + 1 && PS > CELLS, "band shape");
+    __shared__ float sH[2 * HB];
+    __shared__ __attribute__((aligned(16))) float sZ[2 * ZB];
+    __shared__ float sTab[KAN_MAX_TABLE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_r = wave >> 1, w_c = wave & 1, kh2 = lane >> 5;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W;
+    const BlockId blk = xcd_block_order(true);
+    const int grp = blk.y / tiles_o;
+    const int k0 = blk.x * TR, o_tile0 = (blk.y - grp * tiles_o) * TO;
+    x += (size_t)grp * g.C * HW;
+    dz += (size_t)grp * g.O * HoWo;
+    dwp += (size_t)grp * Krows * Opad;
+    const int c0 = k0 / PT;
+
+    if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
+    for (int i = tid; i < 2 * HB; i += NT) sH[i] = 0.f;      // borders stay zero for good
+    float* const dump = sH + CELLS;                           // a pad word of plane 0 that no read touches
+
+    // ---- expansion units of this thread (fixed): unit -> (channel of the tile, halo row, column)
+    int u_src[SLOTS], u_dst[SLOTS], u_hr[SLOTS]; unsigned u_ok = 0;
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int idx = tid + k * NT;
+        const int ch = idx / ((R + 2) * W), rc = idx - ch * ((R + 2) * W), hr = rc / W, col = rc - hr * W;
+        u_src[k] = (c0 + ch) * HW + (hr - 1) * W + col;                    // + image / band part per band
+        u_dst[k] = ch * (P * PS) + hr * HWc + col + 1;
+        u_hr[k] = hr - 1;
+        u_ok |= ((idx < NU && c0 + ch < g.C) ? 1u : 0u) << k;
+    }
+    const kan_rsrc x_rs = make_rsrc(x, x_bytes), dz_rs = make_rsrc(dz, dz_bytes);
+
+    // ---- A-operand addresses: this lane's two tile rows -> (channel, tap, plane) -> plane base + tap shift (+ k-half)
+    unsigned aA[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        int row = k0 + w_r * 64 + mi * 32 + (lane & 31);
+        if (row >= Krows) row = k0;                                         // rows past the end: any valid address (discarded at the store)
+        const int c = row / PT, rem = row - c * PT, tap = rem / P, pl_ = rem - tap * P, r = tap / 3, t = tap - 3 * r;
+        aA[mi] = lds_addr(sH + ((c - c0) * P + pl_) * PS + r * HWc + t + kh2);
+    }
+    // ---- B-operand addresses: one per k-pair (XOR swizzle), the second 32-output block and the buffer are immediates
+    unsigned bB[KPX / 2];
+    {
+        const int ol = w_c * 64 + (lane & 31), sw = (ol >> 1) & 15;
+#pragma unroll
+        for (int kk = 0; kk < KPX / 2; ++kk) bB[kk] = lds_addr(sZ + ol * KPX + ((2 * kk + kh2) ^ sw));
+    }
+    // ---- dz DMA: wave w copies chunks m = 8 w .. 8 w + 7 (64 words = 4 output rows x 16 pixels); lane -> (row, swizzled pixel)
+    unsigned zoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ol = 4 * (wave * 8 + j) + (lane >> 4), q = (lane & 15) ^ ((ol >> 1) & 15);
+        zoff[j] = o_tile0 + ol < g.O ? (unsigned)((o_tile0 + ol) * HoWo + q) * 4u : KAN_OOB;
+    }
+    constexpr int BPI = (W * W) / BP;                         // bands per image (square planes: H == W is checked on the host)
+    auto issue_dz = [&](int band, int st, int zb) {
+        const int b = band / BPI, px0 = (band - b * BPI) * BP + st * KPX;
+        const int soff = __builtin_amdgcn_readfirstlane((b * (int)g.ybs + px0) * 4);
+        float* dst = sZ + zb * ZB + wave * (8 * 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dst + j * 64), 4, (int)zoff[j], soff, 0, 0);
+    };
+    float xv[SLOTS]; unsigned inb_mask = 0;
+    auto load_band = [&](int band) {
+        const int b = band / BPI, h0 = (band - b * BPI) * R;
+        const int sbase = b * (int)g.xbs + h0 * W;
+        inb_mask = 0;
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const bool inb = ((u_ok >> k) & 1u) && (unsigned)(h0 + u_hr[k]) < (unsigned)g.H;
+            xv[k] = buf_load(x_rs, inb ? (unsigned)(sbase + u_src[k]) * 4u : KAN_OOB);
+            inb_mask |= (inb ? 1u : 0u) << k;
+        }
+    };
+    auto expand = [&](int k, int hb) {
+        if ((u_ok >> k) & 1u)
+            stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> k) & 1u, xv[k], xv[k], sH + hb * HB + u_dst[k], PS, dump);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nb0 = blk.z * bands_per_split, nb1 = min(n_bands, nb0 + bands_per_split);
+    __syncthreads();                                          // sTab, zero fill
+    if (nb0 < nb1) {
+        load_band(nb0);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) expand(k, 0);
+        issue_dz(nb0, 0, 0);
+    }
+    int hb = 0;
+    for (int band = nb0; band < nb1; ++band, hb ^= 1) {
+        const unsigned hoff = (unsigned)(hb * HB * 4);
+        const unsigned a0 = aA[0] + hoff, a1 = aA[1] + hoff;
+#pragma unroll
+        for (int st = 0; st < SPB; ++st) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this step's dz landed (own DMAs), the next band's inputs arrived
+            __syncthreads();                                  // ... everybody's; halo of this band visible; previous step's reads done
+            // next step's dz -> the other buffer
+            if (st + 1 < SPB) issue_dz(band, st + 1, (st + 1) & 1);
+            else if (band + 1 < nb1) issue_dz(band + 1, 0, 0);
+            if (st == 0) { if (band + 1 < nb1) load_band(band + 1); }
+            else if (st - 1 < SLOTS) { if (band + 1 < nb1) expand(st - 1, hb ^ 1); }
+            // ---- 8 k-pairs of this step
+            float fa[2][2], fb[2][2];
+#define KAN_OFFA(kk) ((((16 * st + 2 * (kk)) / W) * HWc + ((16 * st + 2 * (kk)) % W)) * 4)
+#define KAN_OFFB(kk) (((st & 1) * ZB) * 4)
+            LDS_READ4W(fa[0][0], fa[0][1], fb[0][0], fb[0][1], a0, a1, bB[0], KAN_OFFA(0), KAN_OFFB(0), KAN_OFFB(0) + 32 * KPX * 4);
+#pragma unroll
+            for (int kk = 0; kk < KPX / 2; ++kk) {
+                const int c_ = kk & 1, n_ = c_ ^ 1;
+                if (kk + 1 < KPX / 2) {
+                    LDS_READ4W(fa[n_][0], fa[n_][1], fb[n_][0], fb[n_][1], a0, a1, bB[kk + 1], KAN_OFFA(kk + 1), KAN_OFFB(kk + 1),
+                               KAN_OFFB(kk + 1) + 32 * KPX * 4);
+                    LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 4);
+                } else {
+                    LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 0);
+                }
+                acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);
+                acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);
+                acc[1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[1][0]);
+                acc[1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[1][1]);
+            }
+#undef KAN_OFFA
+#undef KAN_OFFB
+        }
+    }
+
+    float* out = dwp + (size_t)blk.z * slab_elems;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = k0 + w_r * 64 + mi * 32 + mfma_row(r, lane);
+            if (row >= Krows) continue;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int o = o_tile0 + w_c * 64 + ni * 32 + (lane & 31);
+                out[(size_t)row * Opad + o] = acc[mi][ni][r];
+            }
+        }
+}
+
 // ============================================================================ depthwise (one input channel per group)
 // With C = 1 and O <= 2 per group (kan_mobilenetv2.py:253-255 replace_depthwise) the GEMM tiles above run at 1/128
 // utilisation; these direct kernels do the same arithmetic per output element instead.  They are HBM / VALU bound
@@ -2011,6 +2198,39 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
     c.splits = pick_splits((long long)c.tiles_c * c.tiles_p * ngroups(g), c.chunks, 8, 4.0 * g->B * g->C * g->H * g->W * ngroups(g));
     return c;
 }
+// Halo weight-gradient kernel (k_conv_bwd_weight_halo): 3x3 / stride 1 / pad 1 layers of the default B-spline specs on square
+// 16x16 and 8x8 planes (KAN-VGG layers 1-3), whole 128-output tiles, single input tensor.  Its packed gradient is
+// CHANNEL-major: row = (c*T + tap)*P + p (kan_unpack_wgrad follows).
+bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
+    const int f = fast_variant(b);
+    if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2)) return false;
+    if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
+    if (round_up(g->O, 64) % 128 != 0 || g->C > 65535 / 81) return false;
+    if (want_pix_major(g, b, PM_BWD_WEIGHT)) return false;
+    return g->H == g->W && (g->W == 16 || g->W == 8);
+}
+struct BwHaloCfg { int R, spb, n_bands, tiles_r, tiles_o, splits, bands_per_split; };
+BwHaloCfg bw_halo_cfg(const KanGeom* g, const KanPlan& pl) {
+    BwHaloCfg c;
+    c.R = g->W == 16 ? 4 : 8;
+    c.spb = c.R * g->W / 16;
+    c.n_bands = g->B * (g->H / c.R);
+    c.tiles_r = ceil_div(pl.K, 128);
+    c.tiles_o = pl.Opad / 128;
+    const long long tiles = (long long)c.tiles_r * c.tiles_o * ngroups(g);
+    const double slab_bytes = 4.0 * pl.K * pl.Opad * ngroups(g);
+    int best = 1; double best_cost = -1;
+    for (int sp = 1; sp <= c.n_bands && sp <= 1024; ++sp) {            // the round model of pick_splits, in bands of spb steps
+        const int bps = ceil_div(c.n_bands, sp);
+        if (ceil_div(c.n_bands, bps) != sp) continue;
+        const long long rounds = (tiles * sp + 1023) / 1024;
+        const double cost = (double)(rounds * (bps * c.spb + 6)) + sp * slab_cost_steps(slab_bytes);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    c.splits = best;
+    c.bands_per_split = ceil_div(c.n_bands, best);
+    return c;
+}
 struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits, slots; };
 BwCfg bw_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     BwCfg c;
@@ -2064,7 +2284,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->bwd_weight_slab_elems = (long long)G * pl->K * pl->Opad;
     pl->fwd_splits = fwd_cfg(g, b, *pl).splits;
     pl->bwd_data_splits = bd.splits;
-    pl->bwd_weight_splits = bw_cfg(g, b, *pl).splits;
+    pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
     pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
@@ -2110,6 +2330,7 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
     q.O = g->O; q.C = g->C; q.T = g->kh * g->kw; q.P = pl.P; q.hb = b->act != KAN_ACT_NONE; q.nb = b->n_basis;
     q.IPC = flat ? 1 : pl.IPC; q.KC = flat ? pl.P : pl.KC; q.Opad = pl.Opad;
     q.pair = (!flat && halo_fwd(g, b)) ? 1 : 0;
+    q.cmajor = (flat && halo_bwd_weight(g, b)) ? 1 : 0;
     q.divT = make_fastdiv(q.T); q.divNb = make_fastdiv(q.nb); q.divIPC = make_fastdiv(q.IPC); q.divP = make_fastdiv(q.P);
     return q;
 }
@@ -2476,6 +2697,22 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
 #undef KAN_DWW
         return launch_ok("dw_bwd_weight");
     }
+    if (halo_bwd_weight(g, b) && x == xn) {
+        const BwHaloCfg hc = bw_halo_cfg(g, pl);
+        const DevGeom dgh = dev_geom(g); const DevBasis dbh = dev_basis(b);
+        if ((long long)hc.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
+        dim3 grid(hc.tiles_r, hc.tiles_o * ngroups(g), hc.splits);
+        const int fv = fast_variant(b);
+#define KAN_BWH(F, WV, RV) hipLaunchKernelGGL((k_conv_bwd_weight_halo<F, WV, RV>), grid, dim3(256), 0, (hipStream_t)stream, dz, x, dwp, dgh, dbh, pl.K, \
+        pl.Opad, hc.n_bands, hc.bands_per_split, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4), hc.tiles_o)
+        if (fv == 1 && g->W == 16) KAN_BWH(1, 16, 4);
+        else if (fv == 1) KAN_BWH(1, 8, 8);
+        else if (g->W == 16) KAN_BWH(2, 16, 4);
+        else KAN_BWH(2, 8, 8);
+#undef KAN_BWH
+        return launch_ok("conv_bwd_weight_halo");
+    }
+    if (halo_bwd_weight(g, b)) return fail("internal: the channel-major weight-gradient layout needs x == xn");
     BwCfg c = bw_cfg(g, b, pl);
     DevGeom dg = dev_geom(g);
     dg.pix_major = (x_pm && dz_pm && x == xn && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Register / LDS / spill figures of every kernel in libkanconv.so (from the gfx950 code object's metadata notes).
+usage: kernel_resources.py [substring]"""
+import os, re, struct, subprocess, sys, tempfile
+so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "convolutional-kan-for-image-classification_amd", "libkanconv.so")
+with tempfile.TemporaryDirectory() as d:
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, d + "/fat.bin"], check=True)
+    blob = open(d + "/fat.bin", "rb").read()
+    assert blob[:24] == b"__CLANG_OFFLOAD_BUNDLE__"
+    n, off = struct.unpack("<Q", blob[24:32])[0], 32
+    for _ in range(n):
+        o, sz, tl = struct.unpack("<QQQ", blob[off:off + 24]); off += 24
+        triple = blob[off:off + tl].decode(); off += tl
+        if "gfx950" in triple:
+            open(d + "/dev.co", "wb").write(blob[o:o + sz])
+    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", d + "/dev.co"], capture_output=True, text=True).stdout
+    demangle = lambda s: subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", s], capture_output=True, text=True).stdout.strip()
+for blk in notes.split("- .agpr_count")[1:]:
+    name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+    g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+    short = re.sub(r"\(anonymous namespace\)::|\(.*", "", demangle(name))
+    if len(sys.argv) > 1 and sys.argv[1] not in short:
+        continue
+    print(f"{short:48s} vgpr {g('vgpr_count'):3d} sgpr {g('sgpr_count'):3d} vgpr-spill {g('vgpr_spill_count'):3d} sgpr-spill {g('sgpr_spill_count'):3d} "
+          f"lds {g('group_segment_fixed_size'):6d} scratch {g('private_segment_fixed_size'):4d}")

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libkanconv.so")
 
 KAN_MAX_PLANES = 16
 KAN_MAX_TABLE = 32
+KAN_FP_WORDS = 192
 BASIS_BSPLINE, BASIS_RBF, BASIS_CHEBY, BASIS_POLY, BASIS_FOURIER, BASIS_RELU, BASIS_GRAM = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_IDENTITY, ACT_GELU, ACT_SILU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_GELU_TANH = -1, 0, 1, 2, 3, 4, 5, 6
 
@@ -43,6 +44,8 @@ SIGNATURES = {
     "kan_last_error": (C.c_char_p, []),
     "kan_plan": (_I, [_GP, _BP, C.POINTER(KanPlan)]),
     "kan_pack_weights": (_I, [_P, _P, _P, _P, _GP, _BP, _P]),
+    "kan_pack_cacheable": (_I, [_GP, _BP]),
+    "kan_pack_weights_cached": (_I, [_P, _P, _P, _P, _GP, _BP, _P, _I, _I, _I, _P]),
     "kan_conv_fwd": (_I, [_P, _P, _P, _P, _GP, _BP, _P, _P]),
     "kan_position_major": (_I, [_P, _P, _I, _I, _I, _LL, _P]),
     "kan_conv_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _GP, _BP, _P, _P]),

@@ -182,27 +182,111 @@ __device__ __forceinline__ int pack_row(const PackGeo& q, int src_kind, int j) {
     return wp_row(q, tap, c, p);
 }
 
-// One launch covers both sources: blocks x < nb_base transpose the base weights (src_kind 0), the rest the basis weights.
-__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src_base, const float* __restrict__ src_basis,
-                                              float* __restrict__ wp, PackGeo q, int nb_base, long long wp_gstride) {
-    __shared__ float tile[32][33];
-    const int src_kind = (int)blockIdx.x < nb_base ? 0 : 1;           // block-uniform
-    const int bx = src_kind == 0 ? blockIdx.x : blockIdx.x - nb_base;
-    const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;       // source row length
-    const float* src = (src_kind == 0 ? src_base : src_basis) + (size_t)blockIdx.z * q.O * J;     // group blockIdx.z: stacked sources
-    wp += (size_t)blockIdx.z * wp_gstride;
-    const int j0 = bx * 32, o0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+constexpr int FP_LANES = 64;                        // words per fingerprint slot (KAN_FP_WORDS / 3 in kanconv.h)
+// Content fingerprint of the reference-layout weights: two sums over the elements of bits * m(position) (mod 2^32), accumulated with
+// integer atomics (order-independent, hence deterministic) into ring[cur]; ring is three slots used round-robin, and this
+// launch also clears the slot of the NEXT call (nobody reads it during this one).  kan_pack_weights_cached compares
+// ring[cur] with ring[cur - 1]: equal => the weights are what they were when the packed layouts were last written.
+// `stride` > 1 samples every stride-th group of four elements.
+// Two independent 32-bit sums: h1 = sum bits * (2 pos + 1) (odd multiplier => invertible mod 2^32: a change of any one element
+// moves it) and h2 = sum rotl(bits, pos & 31).  32-bit indices and one quarter-rate multiply per element keep the kernel
+// HBM-bound (with 64-bit index arithmetic and three multiplies per element it ran at 1.1 TB/s, ALU-bound).
+__global__ __launch_bounds__(256) void k_fingerprint(const float* __restrict__ a, unsigned na, const float* __restrict__ b, unsigned nb,
+                                                     unsigned stride, unsigned long long* __restrict__ ring, int cur) {
+    __shared__ unsigned part[2][4];
+    if (blockIdx.x == 0 && threadIdx.x < FP_LANES) ring[((cur + 1) % 3) * FP_LANES + threadIdx.x] = 0ull;
+    unsigned h1 = 0u, h2 = 0u;
+    auto fold = [&](unsigned w, unsigned p) { h1 += w * (2u * p + 1u); h2 += __builtin_rotateleft32(w, p & 31u); };
+    constexpr int U = 8;                                              // independent 16-byte loads in flight per lane
+    const unsigned nthreads = gridDim.x * 256u, tid0 = blockIdx.x * 256u + threadIdx.x;
+    // one pass per tensor over its WHOLE groups of four; loads are unconditional on clamped indices (hipcc puts a
+    // `s_waitcnt vmcnt(0)` behind every load it has to branch around, which left one load in flight: 1.2 TB/s)
+    auto pass = [&](const float* __restrict__ src, unsigned n, unsigned pos_base) {
+        const unsigned nfull = n / 4u, ngr = (nfull + stride - 1u) / stride;             // sampled whole groups
+        if (ngr == 0u) return;
+        for (unsigned i0 = tid0; i0 < ngr; i0 += nthreads * U) {
+            float4 v[U]; unsigned e[U]; bool ok[U];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int o = o0 + ty + 8 * i, j = j0 + tx;
-        tile[ty + 8 * i][tx] = (o < q.O && j < J) ? src[(size_t)o * J + j] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const unsigned i = i0 + u * nthreads;
+                ok[u] = i < ngr;
+                e[u] = (ok[u] ? i : ngr - 1u) * stride * 4u;
+                v[u] = *reinterpret_cast<const float4*>(src + e[u]);   // sources are 16-byte aligned (checked on the host)
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned p = pos_base + e[u];
+                if (ok[u]) { fold(__float_as_uint(v[u].x), p); fold(__float_as_uint(v[u].y), p + 1u); fold(__float_as_uint(v[u].z), p + 2u); fold(__float_as_uint(v[u].w), p + 3u); }
+            }
+        }
+        if (tid0 == 0u) for (unsigned k = nfull * 4u; k < n; ++k) fold(__float_as_uint(src[k]), pos_base + k);     // ragged tail (< 4 elements)
+    };
+    if (na) pass(a, na, 0u);
+    pass(b, nb, na);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { h1 += __shfl_xor(h1, off, 64); h2 += __shfl_xor(h2, off, 64); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = h1; part[1][threadIdx.x >> 6] = h2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned s1 = part[0][0] + part[0][1] + part[0][2] + part[0][3], s2 = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        // the two sums ride in the two halves of a 64-bit word (separate 32-bit atomics: no carry between them); a slot is
+        // FP_LANES words and a block adds to word blockIdx % FP_LANES (thousands of atomics on ONE address cost ~12 ns each)
+        unsigned* w = reinterpret_cast<unsigned*>(ring + cur * FP_LANES + (blockIdx.x % FP_LANES));
+        atomicAdd(w, s1);
+        atomicAdd(w + 1, s2);
+    }
+}
+// `fp` != NULL: the launch is a no-op when slot cur equals slot cur - 1 (weights unchanged since the layouts were written).
+// Called by every thread of a workgroup (contains a barrier); the slot totals are the sums of the slot's FP_LANES words.
+__device__ __forceinline__ bool fp_unchanged(const unsigned long long* fp, int cur) {
+    __shared__ int same;
+    if (!fp) return false;
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x;
+        unsigned lo_c = 0, hi_c = 0, lo_p = 0, hi_p = 0;
+        if (t < FP_LANES) {
+            const unsigned long long c = fp[cur * FP_LANES + t], p = fp[((cur + 2) % 3) * FP_LANES + t];
+            lo_c = (unsigned)c; hi_c = (unsigned)(c >> 32); lo_p = (unsigned)p; hi_p = (unsigned)(p >> 32);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            lo_c += __shfl_xor(lo_c, off, 64); hi_c += __shfl_xor(hi_c, off, 64);
+            lo_p += __shfl_xor(lo_p, off, 64); hi_p += __shfl_xor(hi_p, off, 64);
+        }
+        if (t == 0) same = (lo_c == lo_p && hi_c == hi_p) ? 1 : 0;
     }
     __syncthreads();
+    return same != 0;
+}
+
+// One launch covers both sources: tiles x < nb_base transpose the base weights (src_kind 0), the rest the basis weights.
+// Grid-stride over the (x, y) tiles so that the grid stays small and an unchanged fingerprint costs microseconds.
+__global__ __launch_bounds__(256) void k_pack(const float* __restrict__ src_base, const float* __restrict__ src_basis,
+                                              float* __restrict__ wp, PackGeo q, int nb_base, long long wp_gstride, int tiles_x, int tiles_y,
+                                              const unsigned long long* __restrict__ fp, int fp_cur) {
+    __shared__ float tile[32][33];
+    if (fp_unchanged(fp, fp_cur)) return;
+    wp += (size_t)blockIdx.z * wp_gstride;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    for (int tile_id = blockIdx.x; tile_id < tiles_x * tiles_y; tile_id += gridDim.x) {
+        const int by = tile_id / tiles_x, bx0 = tile_id - by * tiles_x;
+        const int src_kind = bx0 < nb_base ? 0 : 1;                   // block-uniform
+        const int bx = src_kind == 0 ? bx0 : bx0 - nb_base;
+        const int J = src_kind == 0 ? q.C * q.T : q.C * q.nb * q.T;   // source row length
+        const float* src = (src_kind == 0 ? src_base : src_basis) + (size_t)blockIdx.z * q.O * J;     // group blockIdx.z: stacked sources
+        const int j0 = bx * 32, o0 = by * 32;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int j = j0 + ty + 8 * i, o = o0 + tx;
-        if (j < J && o < q.Opad) wp[(size_t)pack_row(q, src_kind, j) * q.Opad + o] = tile[tx][ty + 8 * i];
+        for (int i = 0; i < 4; ++i) {
+            int o = o0 + ty + 8 * i, j = j0 + tx;
+            tile[ty + 8 * i][tx] = (o < q.O && j < J) ? src[(size_t)o * J + j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int j = j0 + ty + 8 * i, o = o0 + tx;
+            if (j < J && o < q.Opad) wp[(size_t)pack_row(q, src_kind, j) * q.Opad + o] = tile[tx][ty + 8 * i];
+        }
+        __syncthreads();
     }
 }
 
@@ -270,15 +354,20 @@ __global__ __launch_bounds__(256) void k_fold_slabs(float* __restrict__ slabs, i
 // i.e. the depth axis (tap, o) is the row, and the 128 columns of one channel tile are contiguous and 16-B aligned.
 // Columns >= CH*P of a half and rows o >= O are zero.
 __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__ wp, float* __restrict__ wd, PackGeo q,
-                                                       int CH, int n_ct, int Opad32, long long wp_gstride) {
+                                                       int CH, int n_ct, int Opad32, long long wp_gstride, int tiles_x, int tiles_y,
+                                                       const unsigned long long* __restrict__ fp, int fp_cur) {
     __shared__ float tile[32][33];
+    if (fp_unchanged(fp, fp_cur)) return;
     const int tap = blockIdx.z;
-    const int oblk = Opad32 / 32, grp = blockIdx.y / oblk;            // groups are folded into grid.y
-    const int col0 = blockIdx.x * 32, o0 = (blockIdx.y - grp * oblk) * 32;   // columns of wd / rows of wd within this tap
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int ncol = n_ct * 128;
-    wp += (size_t)grp * wp_gstride;
-    wd += (size_t)grp * q.T * Opad32 * ncol;
+    const float* const wp0 = wp; float* const wd0 = wd;
+    for (int tile_id = blockIdx.x; tile_id < tiles_x * tiles_y; tile_id += gridDim.x) {      // grid-stride over the (x, y) tiles
+    const int byy = tile_id / tiles_x, bxx = tile_id - byy * tiles_x;
+    const int oblk = Opad32 / 32, grp = byy / oblk;                   // groups are folded into the y tiles
+    const int col0 = bxx * 32, o0 = (byy - grp * oblk) * 32;          // columns of wd / rows of wd within this tap
+    wp = wp0 + (size_t)grp * wp_gstride;
+    wd = wd0 + (size_t)grp * q.T * Opad32 * ncol;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                                   // read wp along o (contiguous)
         int col = col0 + ty + 8 * i, o = o0 + tx;
@@ -297,6 +386,8 @@ __global__ __launch_bounds__(256) void k_pack_bwd_data(const float* __restrict__
         int o = o0 + ty + 8 * i, col = col0 + tx;
         if (o < Opad32 && col < ncol) wd[((size_t)tap * Opad32 + o) * ncol + col] = tile[tx][ty + 8 * i];
     }
+    __syncthreads();
+    }                                                               // tile loop
 }
 
 // ============================================================================ position-major copy
@@ -1940,6 +2031,105 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     }
 }
 
+// Register-resident backward for planes of <= 16 G elements: G lanes per plane, EPL elements per lane, PPI plane groups per
+// loop iteration.  Every load of an iteration is issued up front, unconditionally and on clamped indices (hipcc puts an
+// `s_waitcnt vmcnt(0)` behind each load it has to branch around; the first version of this kernel, one plane group per
+// iteration with guarded loads and a grid capped for the slope atomics, ran at 0.5 - 1.5 TB/s), so that a wave keeps
+// PPI * EPL * 2 loads in flight.  Same arithmetic, in the same order per plane, as k_in_prelu_bwd.  NT = 1024 threads per
+// workgroup where the registers allow: the PReLU-slope gradient costs one same-address atomic per workgroup (~12 ns each,
+// serialised in L2 -- 2048 workgroups set a 25 us floor under the 8x8 ... 2x2 layers), so fewer, fatter workgroups.
+template <int G, int EPL, int PPI, bool POOL, int NT>
+__global__ __launch_bounds__(NT) void k_in_prelu_bwd_regs(const float* __restrict__ dy, const float* __restrict__ z,
+                                                           const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ prelu_a, float* __restrict__ dz,
+                                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dprelu,
+                                                           int n_planes, int Cn, int HW, long long bstride, int prelu_span,
+                                                           const unsigned char* __restrict__ pidx, int W, FastDiv divW) {
+    constexpr int PPB = NT / G;
+    __shared__ double s_da[PPB];
+    const int tid = threadIdx.x, sub = tid % G, pin = tid / G;
+    const bool has_p = prelu_a != nullptr, affine = dgamma != nullptr || dbeta != nullptr;
+    const int n_groups = (n_planes + PPB - 1) / PPB;
+    double sa_total = 0.0;
+    for (int pg0 = blockIdx.x * PPI; pg0 < n_groups; pg0 += gridDim.x * PPI) {
+        float zr[PPI][EPL], gr[PPI][EPL], mu[PPI], rs[PPI]; unsigned char pk[PPI][EPL];
+        size_t base[PPI]; int ch[PPI]; bool act[PPI];
+#pragma unroll
+        for (int q = 0; q < PPI; ++q) {
+            const int plane = (pg0 + q) * PPB + pin;
+            act[q] = plane < n_planes;
+            const int pl = act[q] ? plane : 0;
+            const int b = pl / Cn; ch[q] = pl - b * Cn;
+            base[q] = (size_t)b * bstride + (size_t)ch[q] * HW;
+            mu[q] = mean_i[pl]; rs[q] = rstd_i[pl];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = sub + e * G, ic = i < HW ? i : 0;
+                zr[q][e] = z[base[q] + ic];
+                if (POOL) {
+                    const int h = fastdiv(ic, divW), w = ic - h * W;
+                    const size_t pq = (size_t)pl * (HW >> 2) + (size_t)((h >> 1) * (W >> 1) + (w >> 1));
+                    pk[q][e] = pidx[pq]; gr[q][e] = dy[pq];
+                } else {
+                    pk[q][e] = 0; gr[q][e] = dy[base[q] + ic];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPI; ++q) {
+            const float ga = gamma ? gamma[ch[q]] : 1.f, be = beta ? beta[ch[q]] : 0.f;
+            const float a = has_p ? prelu_a[prelu_span > 0 ? ch[q] / prelu_span : 0] : 1.f;
+            float zc[EPL], dnh[EPL];
+            double s1 = 0.0, s2 = 0.0, sa = 0.0, sg = 0.0, sb = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = sub + e * G;
+                const bool ok = act[q] && i < HW;
+                float g = gr[q][e];
+                if (POOL) {                                   // only the element the forward marked receives the pooled gradient
+                    const int h = fastdiv(i < HW ? i : 0, divW), w = (i < HW ? i : 0) - h * W;
+                    g = pk[q][e] == (unsigned char)((h & 1) * 2 + (w & 1)) ? g : 0.f;
+                }
+                g = ok ? g : 0.f;
+                zc[e] = ok ? zr[q][e] - mu[q] : 0.f;
+                const float nh = zc[e] * rs[q], n = nh * ga + be;
+                const bool neg = has_p && !(n > 0.f);
+                const float dn = neg ? a * g : g;
+                if (neg) sa += (double)n * (double)g;
+                if (affine) { sb += (double)dn; sg += (double)dn * (double)nh; }
+                dnh[e] = dn * ga;
+                s1 += (double)dnh[e]; s2 += (double)dnh[e] * (double)zc[e];
+            }
+            s1 = group_sum<G>(s1); s2 = group_sum<G>(s2);
+            if (has_p) sa = group_sum<G>(sa);
+            if (affine) { sg = group_sum<G>(sg); sb = group_sum<G>(sb); }
+            const double rs_d = (double)rs[q];
+            const double gm = s1 / (double)HW, kk = s2 * rs_d * rs_d / (double)HW;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                const int i = sub + e * G;
+                if (act[q] && i < HW) dz[base[q] + i] = (float)((((double)dnh[e] - gm) - (double)zc[e] * kk) * rs_d);
+            }
+            if (act[q] && sub == 0) {
+                if (dgamma) atomicAdd(&dgamma[ch[q]], (float)sg);
+                if (dbeta) atomicAdd(&dbeta[ch[q]], (float)sb);
+                if (prelu_span > 0) { if (dprelu) atomicAdd(&dprelu[ch[q] / prelu_span], (float)sa); }
+                else sa_total += sa;
+            }
+        }
+    }
+    if (dprelu && prelu_span <= 0) {                // one atomic per workgroup
+        if (sub == 0) s_da[pin] = sa_total;
+        __syncthreads();
+        if (tid == 0) {
+            double t = 0.0;
+            for (int i = 0; i < PPB; ++i) t += s_da[i];
+            atomicAdd(dprelu, (float)t);
+        }
+    }
+}
+
 // ============================================================================ host side
 int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -2354,6 +2544,20 @@ void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, 
     hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
                        dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, make_fastdiv(W > 0 ? W : 1));
 }
+template <int G, int EPL, int PPI>
+void launch_in_bwd_regs(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW,
+                        long long bs, int span, const unsigned char* pidx, int W) {
+    constexpr int NT = EPL * PPI <= 8 ? 1024 : 256;      // (<= 128 VGPRs needed for 1024 threads)
+    const int groups = ceil_div(planes, NT / G);
+    int blocks = ceil_div(groups, PPI);
+    if (blocks > 512 * (1024 / NT)) blocks = 512 * (1024 / NT);
+    const FastDiv dw = make_fastdiv(W > 0 ? W : 1);
+    if (pidx) hipLaunchKernelGGL((k_in_prelu_bwd_regs<G, EPL, PPI, true, NT>), dim3(blocks), dim3(NT), 0, st, dy, z, mean, rstd, gamma, beta, a, dz,
+                                 dgamma, dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, dw);
+    else hipLaunchKernelGGL((k_in_prelu_bwd_regs<G, EPL, PPI, false, NT>), dim3(blocks), dim3(NT), 0, st, dy, z, mean, rstd, gamma, beta, a, dz,
+                            dgamma, dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, dw);
+}
 // Lanes per (b, channel) plane.
 int group_lanes(int HW) {          // (more elements per lane was measured: no gain)
     int g = 4;
@@ -2440,7 +2644,13 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {
     return make_plan(geom, basis, plan);
 }
 
-int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float* wd, const KanGeom* g, const KanBasis* b, void* stream) {
+// Does packing this geometry need wp cleared first (pad rows)?  Cached packing cannot skip a clear conditionally.
+static bool pack_needs_clear(const KanGeom* g, const KanPlan& pl) {
+    return pl.KC != pl.IPC * pl.P || (g->C * g->kh * g->kw) % pl.IPC != 0;
+}
+
+static int pack_weights_impl(const float* w_base, const float* w_basis, float* wp, float* wd, const KanGeom* g, const KanBasis* b,
+                             const unsigned long long* fp, int fp_cur, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     const int hb = b->act != KAN_ACT_NONE;
@@ -2449,6 +2659,7 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
     const int T = g->kh * g->kw, NI = g->C * T, G = ngroups(g);
     const long long wp_gs = (long long)pl.Kpad * pl.Opad;          // floats per group in wp
     PackGeo q = pack_geo(g, b, pl, false);
+    if (fp && (pack_needs_clear(g, pl) || dw_direct(g, b))) return fail("cached packing is not offered for this geometry (kan_pack_cacheable)");
     // rows no source element maps to must be zero: pad rows of every chunk, and the missing items of the last chunk
     if (pl.KC != pl.IPC * pl.P) {                       // (whole-buffer clear only for P that do not divide the step)
         if (hipMemsetAsync(wp, 0, (size_t)pl.packed_weight_bytes, st) != hipSuccess) return fail("memset failed");
@@ -2461,17 +2672,49 @@ int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float
         }
     }
     const int nb_base = hb ? ceil_div(g->C * T, 32) : 0;
-    dim3 grid(nb_base + ceil_div(g->C * b->n_basis * T, 32), pl.Opad / 32, G);
-    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, w_basis, wp, q, nb_base, wp_gs);
+    const int tiles_x = nb_base + ceil_div(g->C * b->n_basis * T, 32), tiles_y = pl.Opad / 32;
+    const long long n_tiles = (long long)tiles_x * tiles_y;
+    dim3 grid((unsigned)(n_tiles < 4096 ? n_tiles : 4096), 1, G);
+    hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, w_basis, wp, q, nb_base, wp_gs, tiles_x, tiles_y, fp, fp_cur);
     if (wd && dw_direct(g, b)) {
         if (hipMemcpyAsync(wd, wp, (size_t)pl.packed_weight_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("memcpy failed");
     } else if (wd) {
         BdCfg c = bd_cfg(g, pl);
-        if ((long long)(c.Opad32 / 32) * G > 65535) return fail("groups * output blocks exceed the grid limit");
-        dim3 gd(c.tiles_c * 4, c.Opad32 / 32 * G, T);
-        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CH, c.tiles_c, c.Opad32, wp_gs);
+        const int bx = c.tiles_c * 4, by = c.Opad32 / 32 * G;
+        const long long nt = (long long)bx * by;
+        dim3 gd((unsigned)(nt < 1024 ? nt : 1024), 1, T);
+        hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CH, c.tiles_c, c.Opad32, wp_gs, bx, by, fp, fp_cur);
     }
     return launch_ok("pack");
+}
+
+int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float* wd, const KanGeom* g, const KanBasis* b, void* stream) {
+    return pack_weights_impl(w_base, w_basis, wp, wd, g, b, nullptr, 0, stream);
+}
+
+int kan_pack_cacheable(const KanGeom* g, const KanBasis* b) {
+    KanPlan pl;
+    if (make_plan(g, b, &pl)) return 0;
+    if ((long long)g->O * g->C * (b->n_basis + 1) * g->kh * g->kw >= (1ll << 31)) return 0;      // 32-bit element positions in the fingerprint
+    return (!pack_needs_clear(g, pl) && !dw_direct(g, b) && ngroups(g) == 1) ? 1 : 0;
+}
+
+int kan_pack_weights_cached(const float* w_base, const float* w_basis, float* wp, float* wd, const KanGeom* g, const KanBasis* b,
+                            unsigned long long* ring, int cur, int force, int sample_stride, void* stream) {
+    static_assert(KAN_FP_WORDS == 3 * FP_LANES, "ring size");
+    if (!ring || cur < 0 || cur > 2 || sample_stride < 1) return fail("bad fingerprint ring arguments");
+    if (!kan_pack_cacheable(g, b)) return fail("cached packing is not offered for this geometry (kan_pack_cacheable)");
+    const int hb = b->act != KAN_ACT_NONE;
+    if ((hb && !w_base) || !w_basis) return fail("null weight pointer");
+    if (((size_t)w_basis & 15) || (hb && ((size_t)w_base & 15))) return fail("cached packing needs 16-byte aligned weight tensors");
+    const int T = g->kh * g->kw;
+    const long long na = hb ? (long long)g->O * g->C * T : 0, nbs = (long long)g->O * g->C * b->n_basis * T;
+    const long long groups4 = ((na + 3) / 4 + (nbs + 3) / 4 + sample_stride - 1) / sample_stride;
+    long long blocks = (groups4 + 256 * 8 - 1) / (256 * 8); if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_fingerprint, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, hb ? w_base : w_basis, (unsigned)na, w_basis,
+                       (unsigned)nbs, (unsigned)sample_stride, ring, cur);
+    if (int rc = launch_ok("fingerprint")) return rc;
+    return pack_weights_impl(w_base, w_basis, wp, wd, g, b, force ? nullptr : ring, cur, stream);
 }
 
 int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const KanGeom* g, const KanBasis* b, void* stream) {
@@ -2800,6 +3043,20 @@ static int instnorm_bwd_any(const float* dy, const float* z, const float* mean, 
     if (!dy || !z || !mean || !rstd || !dz || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_bwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
+    if (HW <= 1024) {                                // register-resident variants: G lanes x EPL elements cover the plane
+#define KAN_INB(G, EPL, PPI) launch_in_bwd_regs<G, EPL, PPI>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W)
+        if (HW <= 4) KAN_INB(4, 1, 4);
+        else if (HW <= 8) KAN_INB(8, 1, 4);
+        else if (HW <= 16) KAN_INB(16, 1, 4);
+        else if (HW <= 32) KAN_INB(32, 1, 4);
+        else if (HW <= 64) KAN_INB(16, 4, 2);       // (8x8 planes: 4 elements per lane, as before)
+        else if (HW <= 128) KAN_INB(64, 2, 2);
+        else if (HW <= 256) KAN_INB(64, 4, 2);
+        else if (HW <= 512) KAN_INB(64, 8, 1);
+        else KAN_INB(64, 16, 1);
+#undef KAN_INB
+        return launch_ok("instnorm_bwd");
+    }
     switch (HW == 64 ? 16 : group_lanes(HW)) {      // 8x8 planes: 4 elements per lane (measured 52 -> 37 us on 256x256x8x8)
         case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
         case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;

@@ -195,18 +195,32 @@ def _stack(ws: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
     return ws[0].unsqueeze(0) if len(ws) == 1 else torch.stack(list(ws))
 
 
-# --------------------------------------------------------------------------------------- packed-weight cache (inference)
-# A forward that needs no gradient at all (eval under torch.no_grad(), frozen layers) re-packs weights that have not
-# changed since the last call: 0.3-0.5 ms of a 5.4 ms KAN-VGG11 forward.  Such calls keep the packed forward layout per
-# (plan key, weight tensors), validated by object identity (weak references), storage address and autograd version
-# counter -- every in-place update, including FusedAdamW's (it bumps the counters), invalidates the entry.
-_PACK_CACHE: "OrderedDict[tuple, tuple]" = OrderedDict()
-_PACK_CACHE_MAX = int(os.environ.get("KAN_PACK_CACHE", "128"))      # entries; 0 disables the cache
+# --------------------------------------------------------------------------------------- persistent packed weights
+# The kernels read the weights in two GEMM layouts (wp forward, wd bwd-data) that only change when the weights do.  Single-group
+# layers keep both layouts alive between calls and re-pack on demand:
+#   * host side, a change of tensor identity, storage address or autograd version counter (every in-place op, optimizer step,
+#     load_state_dict; FusedAdamW bumps the counters of the parameters it updates through raw pointers) forces a re-pack;
+#   * device side, every call fingerprints the reference-layout weights (kan_pack_weights_cached: one pass over the bytes,
+#     ~20 us for an 85 MB layer) and the pack kernels return at once when the fingerprint equals the previous call's.  This is
+#     what catches writes the version counter cannot see -- `p.data.mul_()`, `dist.broadcast(p.data)`, EMA idioms, any
+#     raw-pointer writer.  KAN_PACK_SAMPLE=n (> 1) fingerprints every n-th group of four elements instead of all of them.
+# KAN_PACK_CACHE=0 disables the cache (pack on every call); otherwise it is the number of (layer, geometry) entries kept (LRU).
+_PACKED: "OrderedDict[tuple, PackedWeights]" = OrderedDict()
+_PACK_CACHE_MAX = int(os.environ.get("KAN_PACK_CACHE", "256"))
+_PACK_SAMPLE = max(1, int(os.environ.get("KAN_PACK_SAMPLE", "1")))
+PACK_STATS = {"calls": 0, "forced": 0}               # host-side counters (tests, tools)
+
+
+class PackedWeights:
+    __slots__ = ("wp", "wd", "ring", "cur", "stamps")
+
+    def __init__(self):
+        self.wp = self.wd = self.ring = None
+        self.cur, self.stamps = 0, None
 
 
 class _CallState(threading.local):
-    """Set by the public entry points around Function.apply: inside Function.forward grad mode is always off and
-    ctx.needs_input_grad mirrors requires_grad, so "this call records no graph" has to be observed outside."""
+    """(kept for API symmetry) set by the public entry points around Function.apply."""
     no_grad = False
 
 
@@ -217,22 +231,65 @@ def _records_no_graph(*tensors) -> bool:
     return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
 
 
-def _pack_cache_get(key, weights):
-    hit = _PACK_CACHE.get(key)
-    if hit is None:
-        return None
-    refs, stamps, wp = hit
-    if all(r() is w for r, w in zip(refs, weights)) and stamps == [(w.data_ptr(), w._version) for w in weights]:
-        _PACK_CACHE.move_to_end(key)
-        return wp
-    del _PACK_CACHE[key]
-    return None
+@lru_cache(maxsize=512)
+def _cacheable(plan_key) -> bool:
+    geom, basis, _ = _plan_cached(*plan_key)
+    return bool(L.load().kan_pack_cacheable(C.byref(geom), C.byref(basis)))
 
 
-def _pack_cache_put(key, weights, wp):
-    _PACK_CACHE[key] = ([weakref.ref(w) for w in weights], [(w.data_ptr(), w._version) for w in weights], wp)
-    while len(_PACK_CACHE) > _PACK_CACHE_MAX:
-        _PACK_CACHE.popitem(last=False)
+def _owner(w: torch.Tensor) -> torch.Tensor:
+    """The tensor that owns the storage (1-D layers hand in `weight.unsqueeze(2)` views, fresh objects on every call)."""
+    return w._base if w._base is not None else w
+
+
+def _packed_entry(key, owners):
+    ent = _PACKED.get(key)
+    if ent is None:
+        ent = PackedWeights()
+        _PACKED[key] = ent
+        for o in owners:                              # drop the layouts when a weight tensor dies
+            weakref.finalize(o, _PACKED.pop, key, None)
+        while len(_PACKED) > _PACK_CACHE_MAX:
+            _PACKED.popitem(last=False)
+    else:
+        _PACKED.move_to_end(key)
+    return ent
+
+
+def _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, phases, device, st):
+    """Returns (wp, wd or None): packed afresh, or the layer's persistent layouts brought up to date."""
+    def fresh():
+        wp = torch.empty(plan.packed_weight_bytes // 4, device=device, dtype=torch.float32)
+        wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=device, dtype=torch.float32) if need_dgrad else None
+        wb_all, ws_all = _stack(w_base), _stack(w_basis)          # keep the stacked copies alive until the pack is enqueued
+        L.check(lib.kan_pack_weights(_ptr(wb_all), _ptr(ws_all), _ptr(wp), _ptr(wd), C.byref(geom), C.byref(basis), st), "kan_pack_weights")
+        return wp, wd
+    if _PACK_CACHE_MAX <= 0 or spec.groups != 1 or phases is not None or not _cacheable(plan_key):
+        return fresh()
+    ws, wb = w_basis[0], w_base[0]
+    if (ws.data_ptr() | (wb.data_ptr() if wb is not None else 0)) & 15:
+        return fresh()
+    owners = [_owner(w) for w in (wb, ws) if w is not None]
+    ent = _packed_entry((plan_key, device.index) + tuple(id(o) for o in owners), owners)
+    stamps = [(w.data_ptr(), o._version, tuple(w.shape)) for w, o in zip((w for w in (wb, ws) if w is not None), owners)]
+    force = ent.wp is None or ent.stamps != stamps or (need_dgrad and ent.wd is None)
+    if ent.wp is None:
+        ent.wp = torch.empty(plan.packed_weight_bytes // 4, device=device, dtype=torch.float32)
+        ent.ring = torch.zeros(L.KAN_FP_WORDS, device=device, dtype=torch.int64)
+    if need_dgrad and ent.wd is None:
+        ent.wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=device, dtype=torch.float32)
+    if force:                                         # a graph that saved the old layouts must not be differentiated any more:
+        for t in (ent.wp, ent.wd):                    # autograd's saved-tensor version check raises, as it would for the weights
+            if t is not None:
+                torch.autograd.graph.increment_version(t)
+    # once the bwd-data layout exists it is kept in step with wp on every call (a call that skipped it could re-pack wp alone)
+    L.check(lib.kan_pack_weights_cached(_ptr(wb), _ptr(ws), _ptr(ent.wp), _ptr(ent.wd), C.byref(geom), C.byref(basis),
+                                        C.c_void_p(ent.ring.data_ptr()), ent.cur, int(force), _PACK_SAMPLE, st), "kan_pack_weights_cached")
+    PACK_STATS["calls"] += 1
+    PACK_STATS["forced"] += int(force)
+    ent.cur = (ent.cur + 1) % 3
+    ent.stamps = stamps
+    return ent.wp, (ent.wd if need_dgrad else None)
 
 
 def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True, phases=None, cache_ok: bool = False):
@@ -242,24 +299,13 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     G = spec.groups
     Cg, Og = Ct // G, w_basis[0].shape[0]
     Ot = Og * G
-    geom, basis, plan = _plan_cached(spec, B, Cg, H, W, Og, Ct, Ot)
+    plan_key = (spec, B, Cg, H, W, Og, Ct, Ot)
+    geom, basis, plan = _plan_cached(*plan_key)
     basis = _with_phases(basis, phases)
     Ho, Wo = geom.Ho, geom.Wo
     st = _stream(x)
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
-    cache_ok = cache_ok and not need_dgrad and phases is None and _PACK_CACHE_MAX > 0
-    wlist = [w for w in list(w_base) + list(w_basis) if w is not None]
-    ckey = (spec, B, Cg, H, W, Og, Ct, Ot, x.device.index, tuple(id(w) for w in wlist)) if cache_ok else None
-    wp = _pack_cache_get(ckey, wlist) if cache_ok else None
-    wd = None
-    if wp is None:
-        wp = torch.empty(plan.packed_weight_bytes // 4, device=x.device, dtype=torch.float32)
-        wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=x.device, dtype=torch.float32) if need_dgrad else None
-        wb_all, ws_all = _stack(w_base), _stack(w_basis)          # keep the stacked copies alive until the pack is enqueued
-        L.check(lib.kan_pack_weights(_ptr(wb_all), _ptr(ws_all), _ptr(wp), _ptr(wd), C.byref(geom), C.byref(basis), st), "kan_pack_weights")
-        del wb_all, ws_all
-        if cache_ok:
-            _pack_cache_put(ckey, wlist, wp)
+    wp, wd = _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, phases, x.device, st)
     x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
     _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
             lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),

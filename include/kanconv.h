@@ -31,6 +31,7 @@ extern "C" {
 
 #define KAN_MAX_PLANES 16   /* basis planes per input channel incl. the base-activation plane */
 #define KAN_MAX_TABLE  32   /* knots (B-spline) or centres (RBF) */
+#define KAN_FP_WORDS   192  /* 64-bit words of the fingerprint ring of kan_pack_weights_cached (3 slots x 64) */
 
 /* basis families */
 enum { KAN_BASIS_BSPLINE = 0, KAN_BASIS_RBF = 1, KAN_BASIS_CHEBY = 2, KAN_BASIS_POLY = 3, KAN_BASIS_FOURIER = 4, KAN_BASIS_RELU = 5, KAN_BASIS_GRAM = 6 };
@@ -128,6 +129,20 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
  * stacked on a leading axis, [G,O,C,kh,kw] and [G,O,C*n_basis,kh,kw]. */
 int kan_pack_weights(const float* w_base, const float* w_basis, float* wp, float* wd,
                      const KanGeom* geom, const KanBasis* basis, void* stream);
+
+/* The same with the packed layouts kept by the caller between calls (single-group geometries for which kan_pack_cacheable
+ * returns 1; 16-byte aligned weight tensors).  Every call fingerprints the reference-layout weights on the device -- the two 32-bit sums
+ * sum_i bits_i * (2 i + 1) and sum_i rotl(bits_i, i mod 32), over all elements or over every sample_stride-th group of
+ * four when sample_stride > 1 -- into slot `cur` of `ring`, and the pack kernels return
+ * at once when slot cur equals slot (cur + 2) % 3, i.e. when the weights are bit-for-bit what they were at the previous call: no
+ * host round trip, and writes that bypass the framework's version counters are still seen.  `ring` is KAN_FP_WORDS device words (three slots), zero
+ * before the first call; the caller passes cur = 0, 1, 2, 0, ... on successive calls (the call also clears slot cur + 1).
+ * force != 0 packs unconditionally (first call, new buffers, a weight change the host already knows of).  wd may be NULL (no
+ * bwd-data layout wanted): a later call that wants it must pass force. */
+int kan_pack_cacheable(const KanGeom* geom, const KanBasis* basis);
+int kan_pack_weights_cached(const float* w_base, const float* w_basis, float* wp, float* wd,
+                            const KanGeom* geom, const KanBasis* basis, unsigned long long* ring, int cur, int force,
+                            int sample_stride, void* stream);
 
 /* Fused forward:  z = act(x) (*) W_base + sum_k basis_k(xn) (*) W_basis[:, c*n+k]
  * with zero padding applied to the EXPANDED operand.  Replaces

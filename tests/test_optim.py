@@ -123,31 +123,56 @@ def test_train_model_generic_reduces_loss(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_packed_weight_cache_follows_every_weight_update(gpu_lib):
-    """No-grad forwards reuse the packed weights (ops._PACK_CACHE); an in-place update -- torch's or FusedAdamW's raw-pointer
-    kernel -- must invalidate them.  The grad-enabled forward never uses the cache and serves as the check."""
+def test_packed_weights_follow_every_weight_update(gpu_lib):
+    """Single-group layers keep their packed weight layouts between calls (ops._PACKED).  Every way of changing the weights must
+    be seen: in-place ops (version counter), FusedAdamW's raw-pointer kernel (it bumps the counters), and writes the counters
+    cannot see -- `.data` ops, a raw copy into the storage -- which the device-side fingerprint catches.  The check is a
+    fresh, cache-free pack of the same weights (KAN_PACK_CACHE=0 path)."""
     from convkan_amd import ops
     if ops._PACK_CACHE_MAX <= 0:
         pytest.skip("packed-weight cache disabled (KAN_PACK_CACHE=0)")
     torch.manual_seed(0)
     layer = K.KANConv2DLayer(8, 128, 3, padding=1).cuda()
     x = torch.randn(4, 8, 8, 8, device="cuda")
-    ops._PACK_CACHE.clear()
+
+    def uncached():
+        keep, ops._PACK_CACHE_MAX = ops._PACK_CACHE_MAX, 0
+        try:
+            with torch.no_grad():
+                return layer(x)
+        finally:
+            ops._PACK_CACHE_MAX = keep
+    ops._PACKED.clear()
+    ops.PACK_STATS.update(calls=0, forced=0)
     with torch.no_grad():
         y0 = layer(x)
-        n_entries = len(ops._PACK_CACHE)
         y1 = layer(x)
-    assert n_entries == 1 and len(ops._PACK_CACHE) == 1 and torch.equal(y0, y1)
-    assert torch.equal(layer(x).detach(), y0) and len(ops._PACK_CACHE) == 1          # the training forward neither reads nor fills it
+    assert len(ops._PACKED) == 1 and ops.PACK_STATS == {"calls": 2, "forced": 1} and torch.equal(y0, y1) and torch.equal(y0, uncached())
+    assert torch.equal(layer(x).detach(), y0)                                        # the training forward shares the layouts (+ wd: one forced pack)
     with torch.no_grad():
         layer.spline_conv[0].weight.mul_(1.5)                                        # version counter moves
         y2 = layer(x)
-    assert not torch.equal(y2, y0) and torch.equal(layer(x).detach(), y2)
+    assert not torch.equal(y2, y0) and torch.equal(y2, uncached())
+    forced = ops.PACK_STATS["forced"]
+    layer.spline_conv[0].weight.data.mul_(0.5)                                       # invisible to the version counter
+    layer.base_conv[0].weight.data[3, 2, 1, 1] = 7.0                                 # a single element
+    with torch.no_grad():
+        y3 = layer(x)
+    assert ops.PACK_STATS["forced"] == forced                                        # the host saw nothing ...
+    assert not torch.equal(y3, y2) and torch.equal(y3, uncached())                   # ... the fingerprint did
     opt = K.FusedAdamW(layer.parameters(), lr=1e-2)
     with torch.no_grad():
-        y3 = layer(x)                                                                # cached against the flattened parameters
+        y4 = layer(x)                                                                # parameters now live in the optimizer's flat block
+    assert torch.equal(y4, y3)
     layer(x).square().mean().backward()
     opt.step()
     with torch.no_grad():
-        y4 = layer(x)
-    assert not torch.equal(y4, y3) and torch.equal(layer(x).detach(), y4)
+        y5 = layer(x)
+    assert not torch.equal(y5, y4) and torch.equal(y5, uncached())
+    # a graph that saved the old bwd-data layout must not be differentiated after the weights moved
+    out = layer(x.requires_grad_(True)).square().mean()
+    with torch.no_grad():
+        layer.spline_conv[0].weight.add_(0.01)
+        layer(x)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.backward()

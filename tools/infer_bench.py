@@ -18,7 +18,7 @@ def main():
     x = torch.randn(256, 3, 32, 32, device="cuda")
     out = {}
     for name, entries in (("cached", 128), ("repack_every_call", 0)):
-        ops._PACK_CACHE.clear(); ops._PACK_CACHE_MAX = entries
+        ops._PACKED.clear(); ops._PACK_CACHE_MAX = entries
         with torch.no_grad():
             for _ in range(5):
                 m(x)

@@ -14,7 +14,7 @@ with tempfile.TemporaryDirectory() as d:
         if "gfx950" in triple:
             open(d + "/dev.co", "wb").write(blob[o:o + sz])
     notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", d + "/dev.co"], capture_output=True, text=True).stdout
-    demangle = lambda s: subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", s], capture_output=True, text=True).stdout.strip()
+    demangle = lambda s: subprocess.run(["c++filt", s], capture_output=True, text=True).stdout.strip()
 for blk in notes.split("- .agpr_count")[1:]:
     name = re.search(r"\.name:\s+(\S+)", blk).group(1)
     g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))

@@ -2031,6 +2031,117 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     }
 }
 
+// Register-resident forward for planes of <= 16 G elements: one read of the slabs, statistics and the normalised output from
+// registers (k_in_prelu_fwd reads the summed plane three times and keeps one plane group in flight: 0.5 - 1 TB/s on the
+// 8x8 layers).  Loads are unconditional on clamped indices, PPI plane groups per iteration.
+//   POOL = false: lane `sub` of a plane holds elements sub + e G.
+//   POOL = true : lane `sub` holds the 2x2 windows sub + w G (EPL = 4 windows-per-lane elements, two float2 loads per window),
+//                 so that the fused MaxPool2d(2, 2) needs no neighbour exchange.  W, H even (checked on the host).
+template <int G, int EPL, int PPI, bool POOL, int NT>
+__global__ __launch_bounds__(NT) void k_in_prelu_fwd_regs(const float* z, int n_slabs, long long slab_elems, float* z_out,     // z_out may alias z (slab 0)
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ prelu_a, float* __restrict__ y,
+                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o, int n_planes, int Cn, int HW,
+                                                          long long bstride, float eps, int prelu_span, unsigned char* __restrict__ pidx, int W,
+                                                          FastDiv divW2) {
+    constexpr int PPB = NT / G, WPL = EPL / 4;
+    static_assert(!POOL || EPL % 4 == 0, "pooled variant: whole windows per lane");
+    const int tid = threadIdx.x, sub = tid % G, pin = tid / G;
+    const bool need_sum = (n_slabs > 1) || (z_out != z), has_p = prelu_a != nullptr;
+    const int n_groups = (n_planes + PPB - 1) / PPB, W2 = W >> 1, NWIN = HW >> 2;
+    for (int pg0 = blockIdx.x * PPI; pg0 < n_groups; pg0 += gridDim.x * PPI) {
+        float v[PPI][EPL]; int eo[EPL]; bool eok[EPL];
+        size_t base[PPI]; int ch[PPI], pln[PPI]; bool act[PPI];
+        // element offsets inside a plane (the same for every plane group)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            if (POOL) {
+                const int win = sub + (e >> 2) * G, wc = win < NWIN ? win : 0, h2 = fastdiv(wc, divW2), w2 = wc - h2 * W2;
+                eo[e] = (2 * h2 + ((e >> 1) & 1)) * W + 2 * w2 + (e & 1);
+                eok[e] = win < NWIN;
+            } else {
+                const int i = sub + e * G;
+                eo[e] = i < HW ? i : 0; eok[e] = i < HW;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPI; ++q) {
+            const int plane = (pg0 + q) * PPB + pin;
+            act[q] = plane < n_planes;
+            pln[q] = act[q] ? plane : 0;
+            const int b = pln[q] / Cn; ch[q] = pln[q] - b * Cn;
+            base[q] = (size_t)b * bstride + (size_t)ch[q] * HW;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[q][e] = 0.f;
+        }
+        for (int sl = 0; sl < n_slabs; ++sl) {               // fixed order => deterministic
+            const float* zs = z + (size_t)sl * slab_elems;
+#pragma unroll
+            for (int q = 0; q < PPI; ++q) {
+                if (POOL) {
+#pragma unroll
+                    for (int e = 0; e < EPL; e += 2) {
+                        const float2 t = *reinterpret_cast<const float2*>(zs + base[q] + eo[e]);
+                        v[q][e] += t.x; v[q][e + 1] += t.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) v[q][e] += zs[base[q] + eo[e]];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < PPI; ++q) {
+            double s = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) s += (act[q] && eok[e]) ? (double)v[q][e] : 0.0;
+            const double mu_d = group_sum<G>(s) / (double)HW;
+            double qq = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) { const double d = (double)v[q][e] - mu_d; qq += (act[q] && eok[e]) ? d * d : 0.0; }
+            const double var = group_sum<G>(qq) / (double)HW;
+            const float mu = (float)mu_d, rs = (float)(1.0 / sqrt(var + (double)eps));
+            const float ga = gamma ? gamma[ch[q]] : 1.f, be = beta ? beta[ch[q]] : 0.f;
+            const float a = has_p ? prelu_a[prelu_span > 0 ? ch[q] / prelu_span : 0] : 1.f;
+            if (!act[q]) continue;
+            if (need_sum) {
+                if (POOL) {
+#pragma unroll
+                    for (int e = 0; e < EPL; e += 2)
+                        if (eok[e]) *reinterpret_cast<float2*>(z_out + base[q] + eo[e]) = make_float2(v[q][e], v[q][e + 1]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) if (eok[e]) z_out[base[q] + eo[e]] = v[q][e];
+                }
+            }
+            if (POOL) {
+#pragma unroll
+                for (int w = 0; w < WPL; ++w) {
+                    const int win = sub + w * G;
+                    if (win >= NWIN) continue;
+                    float best = 0.f; int arg = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {                       // scan order (0,0) (0,1) (1,0) (1,1): first maximum wins, NaN wins
+                        const float n = (v[q][4 * w + k] - mu) * rs * ga + be;
+                        const float val = (has_p && !(n > 0.f)) ? a * n : n;
+                        if (k == 0 || val > best || val != val) { best = val; arg = k; }
+                    }
+                    const size_t po = (size_t)pln[q] * NWIN + win;
+                    y[po] = best; pidx[po] = (unsigned char)arg;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (!eok[e]) continue;
+                    const float n = (v[q][e] - mu) * rs * ga + be;
+                    y[base[q] + eo[e]] = (has_p && !(n > 0.f)) ? a * n : n;
+                }
+            }
+            if (sub == 0) { mean_o[pln[q]] = mu; rstd_o[pln[q]] = rs; }
+        }
+    }
+}
+
 // Register-resident backward for planes of <= 16 G elements: G lanes per plane, EPL elements per lane, PPI plane groups per
 // loop iteration.  Every load of an iteration is issued up front, unconditionally and on clamped indices (hipcc puts an
 // `s_waitcnt vmcnt(0)` behind each load it has to branch around; the first version of this kernel, one plane group per
@@ -2544,6 +2655,17 @@ void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, 
     hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
                        dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, make_fastdiv(W > 0 ? W : 1));
 }
+template <int G, int EPL, int PPI, bool POOL>
+void launch_in_fwd_regs(hipStream_t st, int planes, const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma,
+                        const float* beta, const float* a, float* y, float* mean, float* rstd, int Cn, int HW, long long bs, float eps, int span,
+                        unsigned char* pidx, int W) {
+    constexpr int NT = 256;
+    const int groups = ceil_div(planes, NT / G);
+    int blocks = ceil_div(groups, PPI);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((k_in_prelu_fwd_regs<G, EPL, PPI, POOL, NT>), dim3(blocks), dim3(NT), 0, st, z, n_slabs, slab_elems, z_out, gamma, beta, a, y,
+                       mean, rstd, planes, Cn, HW, bs, eps, span, pidx, W, make_fastdiv(W > 1 ? W / 2 : 1));
+}
 template <int G, int EPL, int PPI>
 void launch_in_bwd_regs(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                         const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW,
@@ -3012,6 +3134,31 @@ static int instnorm_fwd_any(const float* z, int n_slabs, long long slab_elems, f
     if (!z || !z_out || !y || !mean || !rstd || n_slabs < 1 || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_fwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
+#define KAN_INF(G, EPL, PPI, POOL) launch_in_fwd_regs<G, EPL, PPI, POOL>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W)
+    if (pidx && HW <= 1024 && ((bstride | HW) & 1) == 0 && (((size_t)z | (size_t)z_out) & 7) == 0 && (slab_elems & 1) == 0) {   // lanes own 2x2 windows (float2 accesses)
+        const int nwin = HW / 4;
+        if (nwin <= 4) KAN_INF(4, 4, 2, true);
+        else if (nwin <= 8) KAN_INF(8, 4, 2, true);
+        else if (nwin <= 16) KAN_INF(16, 4, 2, true);
+        else if (nwin <= 32) KAN_INF(32, 4, 2, true);
+        else if (nwin <= 64) KAN_INF(64, 4, 2, true);
+        else if (nwin <= 128) KAN_INF(64, 8, 1, true);
+        else KAN_INF(64, 16, 1, true);
+        return launch_ok("instnorm_fwd");
+    }
+    if (!pidx && HW <= 1024) {
+        if (HW <= 4) KAN_INF(4, 1, 4, false);
+        else if (HW <= 8) KAN_INF(8, 1, 4, false);
+        else if (HW <= 16) KAN_INF(16, 1, 4, false);
+        else if (HW <= 32) KAN_INF(32, 1, 4, false);
+        else if (HW <= 64) KAN_INF(16, 4, 2, false);
+        else if (HW <= 128) KAN_INF(64, 2, 2, false);
+        else if (HW <= 256) KAN_INF(64, 4, 2, false);
+        else if (HW <= 512) KAN_INF(64, 8, 1, false);
+        else KAN_INF(64, 16, 1, false);
+        return launch_ok("instnorm_fwd");
+    }
+#undef KAN_INF
     switch (group_lanes(HW)) {
         case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
         case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;

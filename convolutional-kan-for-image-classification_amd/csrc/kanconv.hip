@@ -1525,22 +1525,22 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
     asm volatile("ds_read_b32 %0, %4 offset:%7\n\tds_read_b32 %1, %5 offset:%7\n\tds_read_b32 %2, %6 offset:%8\n\tds_read_b32 %3, %6 offset:%9" \
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(a0), "v"(a1), "v"(b), "n"(oA), "n"(oB0), "n"(oB1) : "memory")
 
-template <int FAST, int W, int R>
+template <int FAST, int W, int R, int NIMG>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
     const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dwp, DevGeom g, DevBasis bs, int Krows, int Opad,
     int n_bands, int bands_per_split, long long slab_elems, unsigned x_bytes, unsigned dz_bytes, int tiles_o) {
     constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : KAN_BASIS_BSPLINE;
     constexpr int P = fast_planes(FAST), T = 9, PT = P * T;
     constexpr int TR = 128, TO = 128, NT = 256, KPX = 16;
-    constexpr int HWc = W + 2, CELLS = (R + 2) * HWc;
-    constexpr int PS = W == 16 ? CELLS + 1 : W == 8 ? CELLS + 3 : CELLS + 1;     // plane stride: 2-way conflicts at worst on the A reads (brute-forced)
+    constexpr int HWc = W + 2, HIMG = (R + 2) * HWc, CELLS = NIMG * HIMG;        // a band is NIMG images x R rows (NIMG > 1: whole images)
+    constexpr int PS = W == 16 ? CELLS + 1 : W == 8 ? CELLS + 3 : W == 4 ? CELLS + 7 : CELLS + 1;   // plane stride: 2-way conflicts at worst on the A reads (brute-forced)
     constexpr int NCH = (TR + PT - 2) / PT + 1;              // channels a 128-row tile can touch
     constexpr int HB = NCH * P * PS;                         // floats per halo buffer
-    constexpr int BP = R * W, SPB = BP / KPX;                // pixels / MFMA steps per band
+    constexpr int BP = NIMG * R * W, SPB = BP / KPX;         // pixels / MFMA steps per band
     constexpr int ZB = KPX * TO;                             // floats per dz buffer
-    constexpr int NU = NCH * (R + 2) * W;                    // expansions per band (halo rows included, halo columns are borders)
+    constexpr int NU = NCH * NIMG * (R + 2) * W;             // expansions per band (halo rows included, halo columns are borders)
     constexpr int SLOTS = (NU + NT - 1) / NT;
-    static_assert(BP % KPX == 0 && SPB % 2 == 0 && SPB >= SLOTS + 1 && PS > CELLS, "band shape");
+    static_assert(BP % KPX == 0 && SPB % 2 == 0 && SPB >= SLOTS + 1 && PS > CELLS && (NIMG == 1 || R == W), "band shape");
     __shared__ float sH[2 * HB];
     __shared__ __attribute__((aligned(16))) float sZ[2 * ZB];
     __shared__ float sTab[KAN_MAX_TABLE];
@@ -1566,9 +1566,10 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int idx = tid + k * NT;
-        const int ch = idx / ((R + 2) * W), rc = idx - ch * ((R + 2) * W), hr = rc / W, col = rc - hr * W;
-        u_src[k] = (c0 + ch) * HW + (hr - 1) * W + col;                    // + image / band part per band
-        u_dst[k] = ch * (P * PS) + hr * HWc + col + 1;
+        constexpr int UPC = NIMG * (R + 2) * W, UPI = (R + 2) * W;        // units per channel / per image
+        const int ch = idx / UPC, ri = idx - ch * UPC, img = ri / UPI, rc = ri - img * UPI, hr = rc / W, col = rc - hr * W;
+        u_src[k] = (c0 + ch) * HW + img * (int)g.xbs + (hr - 1) * W + col;    // + image / band part per band
+        u_dst[k] = ch * (P * PS) + img * HIMG + hr * HWc + col + 1;
         u_hr[k] = hr - 1;
         u_ok |= ((idx < NU && c0 + ch < g.C) ? 1u : 0u) << k;
     }
@@ -1597,9 +1598,10 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
         const int ol = 4 * (wave * 8 + j) + (lane >> 4), q = (lane & 15) ^ ((ol >> 1) & 15);
         zoff[j] = o_tile0 + ol < g.O ? (unsigned)((o_tile0 + ol) * HoWo + q) * 4u : KAN_OOB;
     }
-    constexpr int BPI = (W * W) / BP;                         // bands per image (square planes: H == W is checked on the host)
+    constexpr int BPI = NIMG > 1 ? 1 : (W * W) / BP;          // bands per image (square planes: H == W is checked on the host)
     auto issue_dz = [&](int band, int st, int zb) {
-        const int b = band / BPI, px0 = (band - b * BPI) * BP + st * KPX;
+        const int gpx = band * BP + st * KPX;                  // pixel index in (image, position) order; a step never straddles images
+        const int b = gpx / (W * W), px0 = gpx - b * (W * W);
         const int soff = __builtin_amdgcn_readfirstlane((b * (int)g.ybs + px0) * 4);
         float* dst = sZ + zb * ZB + wave * (8 * 64);
 #pragma unroll
@@ -1608,7 +1610,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
     };
     float xv[SLOTS]; unsigned inb_mask = 0;
     auto load_band = [&](int band) {
-        const int b = band / BPI, h0 = (band - b * BPI) * R;
+        const int b = NIMG > 1 ? band * NIMG : band / BPI, h0 = NIMG > 1 ? 0 : (band - b * BPI) * R;
         const int sbase = b * (int)g.xbs + h0 * W;
         inb_mask = 0;
 #pragma unroll
@@ -1654,7 +1656,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
             else if (st - 1 < SLOTS) { if (band + 1 < nb1) expand(st - 1, hb ^ 1); }
             // ---- 8 k-pairs of this step
             float fa[2][2], fb[2][2];
-#define KAN_OFFA(kk) ((((16 * st + 2 * (kk)) / W) * HWc + ((16 * st + 2 * (kk)) % W)) * 4)
+#define KAN_OFFA(kk) ((((16 * st + 2 * (kk)) / (R * W)) * HIMG + (((16 * st + 2 * (kk)) % (R * W)) / W) * HWc + ((16 * st + 2 * (kk)) % W)) * 4)
 #define KAN_OFFB(kk) (((st & 1) * ZB) * 4)
             LDS_READ4W(fa[0][0], fa[0][1], fb[0][0], fb[0][1], a0, a1, bB[0], KAN_OFFA(0), KAN_OFFB(0), KAN_OFFB(0) + 32 * KPX * 4);
 #pragma unroll
@@ -2507,15 +2509,21 @@ bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
     if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2)) return false;
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
     if (round_up(g->O, 64) % 128 != 0 || g->C > 65535 / 81) return false;
-    if (want_pix_major(g, b, PM_BWD_WEIGHT)) return false;
-    return g->H == g->W && (g->W == 16 || g->W == 8);
+    if (g->H != g->W) return false;
+    // 4x4 planes: two images per band, dense (31 % of the products multiply padding).  The position-major tap-skipping launch
+    // wins where it has enough row tiles to balance its unequal taps (measured: 512 -> 512 142 TFLOP/s dense-equivalent against
+    // 134 here; 256 -> 512 118 against 134), so it keeps the wide layers.
+    if (g->W == 4) return g->B % 2 == 0 && g->C <= 256;
+    return g->W == 16 || g->W == 8;
 }
-struct BwHaloCfg { int R, spb, n_bands, tiles_r, tiles_o, splits, bands_per_split; };
+bool pm_bwd_weight(const KanGeom* g, const KanBasis* b) { return want_pix_major(g, b, PM_BWD_WEIGHT) && !halo_bwd_weight(g, b); }
+struct BwHaloCfg { int R, nimg, spb, n_bands, tiles_r, tiles_o, splits, bands_per_split; };
 BwHaloCfg bw_halo_cfg(const KanGeom* g, const KanPlan& pl) {
     BwHaloCfg c;
-    c.R = g->W == 16 ? 4 : 8;
-    c.spb = c.R * g->W / 16;
-    c.n_bands = g->B * (g->H / c.R);
+    c.R = g->W == 16 ? 4 : g->W;
+    c.nimg = g->W == 4 ? 2 : 1;
+    c.spb = c.nimg * c.R * g->W / 16;
+    c.n_bands = g->B * (g->H / c.R) / c.nimg;
     c.tiles_r = ceil_div(pl.K, 128);
     c.tiles_o = pl.Opad / 128;
     const long long tiles = (long long)c.tiles_r * c.tiles_o * ngroups(g);
@@ -2535,7 +2543,7 @@ BwHaloCfg bw_halo_cfg(const KanGeom* g, const KanPlan& pl) {
 struct BwCfg { int TR, TO, tiles_r, tiles_o, chunks, splits, slots; };
 BwCfg bw_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     BwCfg c;
-    c.TO = (big_tiles(b, pl) && !want_pix_major(g, b, PM_BWD_WEIGHT)) ? 256 : (pl.Opad % 128 == 0) ? 128 : 64;
+    c.TO = (big_tiles(b, pl) && !pm_bwd_weight(g, b)) ? 256 : (pl.Opad % 128 == 0) ? 128 : 64;
     c.slots = c.TO == 256 ? 512 : 1024;
     c.TR = c.TO == 64 ? 256 : 128;
     c.tiles_r = ceil_div(pl.K, c.TR);
@@ -2586,8 +2594,8 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_splits = fwd_cfg(g, b, *pl).splits;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
-    pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
-    pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
+    pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || pm_bwd_weight(g, b)) ? 1 : 0;
+    pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     if (dw_direct(g, b)) {                          // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
@@ -2602,7 +2610,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
         pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * G, &pl->fwd_splits, fc.slots);
     }
-    if (want_pix_major(g, b, PM_BWD_WEIGHT)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
+    if (pm_bwd_weight(g, b)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
         LiveClass cw[32]; BwCfg wc = bw_cfg(g, b, *pl);
         const long long tiles_per_tap = (long long)ceil_div((long long)g->C * pl->P, wc.TR) * wc.tiles_o * G;
         for (int tap = 0; tap < T; ++tap) cw[tap] = LiveClass{tiles_per_tap, live_positions_for_tap(g, tap) * ceil_div(g->B, 16)};
@@ -2796,7 +2804,8 @@ static int pack_weights_impl(const float* w_base, const float* w_basis, float* w
     const int nb_base = hb ? ceil_div(g->C * T, 32) : 0;
     const int tiles_x = nb_base + ceil_div(g->C * b->n_basis * T, 32), tiles_y = pl.Opad / 32;
     const long long n_tiles = (long long)tiles_x * tiles_y;
-    dim3 grid((unsigned)(n_tiles < 4096 ? n_tiles : 4096), 1, G);
+    const long long cap = fp ? 1024 : 4096;             // cached mode: the usual outcome is an early exit, keep the grid small
+    dim3 grid((unsigned)(n_tiles < cap ? n_tiles : cap), 1, G);
     hipLaunchKernelGGL(k_pack, grid, dim3(256), 0, st, w_base, w_basis, wp, q, nb_base, wp_gs, tiles_x, tiles_y, fp, fp_cur);
     if (wd && dw_direct(g, b)) {
         if (hipMemcpyAsync(wd, wp, (size_t)pl.packed_weight_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail("memcpy failed");
@@ -2804,7 +2813,8 @@ static int pack_weights_impl(const float* w_base, const float* w_basis, float* w
         BdCfg c = bd_cfg(g, pl);
         const int bx = c.tiles_c * 4, by = c.Opad32 / 32 * G;
         const long long nt = (long long)bx * by;
-        dim3 gd((unsigned)(nt < 1024 ? nt : 1024), 1, T);
+        const long long capd = fp ? 128 : 1024;
+        dim3 gd((unsigned)(nt < capd ? nt : capd), 1, T);
         hipLaunchKernelGGL(k_pack_bwd_data, gd, dim3(256), 0, st, (const float*)wp, wd, q, c.CH, c.tiles_c, c.Opad32, wp_gs, bx, by, fp, fp_cur);
     }
     return launch_ok("pack");
@@ -3068,19 +3078,21 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
         if ((long long)hc.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
         dim3 grid(hc.tiles_r, hc.tiles_o * ngroups(g), hc.splits);
         const int fv = fast_variant(b);
-#define KAN_BWH(F, WV, RV) hipLaunchKernelGGL((k_conv_bwd_weight_halo<F, WV, RV>), grid, dim3(256), 0, (hipStream_t)stream, dz, x, dwp, dgh, dbh, pl.K, \
+#define KAN_BWH(F, WV, RV, NV) hipLaunchKernelGGL((k_conv_bwd_weight_halo<F, WV, RV, NV>), grid, dim3(256), 0, (hipStream_t)stream, dz, x, dwp, dgh, dbh, pl.K, \
         pl.Opad, hc.n_bands, hc.bands_per_split, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4), hc.tiles_o)
-        if (fv == 1 && g->W == 16) KAN_BWH(1, 16, 4);
-        else if (fv == 1) KAN_BWH(1, 8, 8);
-        else if (g->W == 16) KAN_BWH(2, 16, 4);
-        else KAN_BWH(2, 8, 8);
+        if (fv == 1 && g->W == 16) KAN_BWH(1, 16, 4, 1);
+        else if (fv == 1 && g->W == 8) KAN_BWH(1, 8, 8, 1);
+        else if (fv == 1) KAN_BWH(1, 4, 4, 2);
+        else if (g->W == 16) KAN_BWH(2, 16, 4, 1);
+        else if (g->W == 8) KAN_BWH(2, 8, 8, 1);
+        else KAN_BWH(2, 4, 4, 2);
 #undef KAN_BWH
         return launch_ok("conv_bwd_weight_halo");
     }
     if (halo_bwd_weight(g, b)) return fail("internal: the channel-major weight-gradient layout needs x == xn");
     BwCfg c = bw_cfg(g, b, pl);
     DevGeom dg = dev_geom(g);
-    dg.pix_major = (x_pm && dz_pm && x == xn && want_pix_major(g, b, PM_BWD_WEIGHT)) ? 1 : 0;
+    dg.pix_major = (x_pm && dz_pm && x == xn && pm_bwd_weight(g, b)) ? 1 : 0;
     if (dg.pix_major) { x = x_pm; xn = x_pm; dz = dz_pm; }
     DevBasis db = dev_basis(b);
     hipStream_t st = (hipStream_t)stream;

@@ -532,21 +532,23 @@ class _KanConvInPrelu(torch.autograd.Function):
             rstd = torch.empty_like(mean)
             # all groups in one launch: per-channel gamma/beta concatenated, one PReLU slope per Og channels
             gamma, beta, slope = _cat(gammas), _cat(betas), _cat(prelus)
+            # summed pre-norm values (saved for the backward): slab 0 itself when there is one slab, else a tensor of their own, so
+            # that the S-slab buffer can be freed (was: summed in place into slab 0, then cloned out of the buffer)
+            z = zs[0] if S == 1 else torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
             pidx = None
             if pool:                                     # MaxPool2d(2, 2) fused behind the PReLU: the full-size y is never written
                 if Ho % 2 or Wo % 2:
                     raise L.KanConvError(f"fused 2x2 max-pool needs an even plane, got {Ho}x{Wo}")
                 y = torch.empty((B, Ot, Ho // 2, Wo // 2), device=x.device, dtype=torch.float32)
                 pidx = torch.empty((B, Ot, Ho // 2, Wo // 2), device=x.device, dtype=torch.uint8)
-                L.check(lib.kan_instnorm_prelu_pool_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(zs), _ptr(gamma), _ptr(beta), _ptr(slope),
+                L.check(lib.kan_instnorm_prelu_pool_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(z), _ptr(gamma), _ptr(beta), _ptr(slope),
                                                         _ptr(y), C.c_void_p(pidx.data_ptr()), _ptr(mean), _ptr(rstd), B, Ot, Ho, Wo,
                                                         Ot * HW, eps, Og if G > 1 else 0, _stream(x)), "kan_instnorm_prelu_pool_fwd")
             else:
                 y = torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
-                L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(zs), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(y),
+                L.check(lib.kan_instnorm_prelu_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(z), _ptr(gamma), _ptr(beta), _ptr(slope), _ptr(y),
                                                    _ptr(mean), _ptr(rstd), B, Ot, HW, Ot * HW, eps, Og if G > 1 else 0, _stream(x)),
                         "kan_instnorm_prelu_fwd")
-        z = zs[0] if S == 1 else zs[0].clone()          # summed pre-norm values; clone drops the other slabs
         ctx.spec, ctx.flags = spec, (use_affine, use_prelu, pool)
         ctx.wids = (id(w_base[0]) if spec.has_base else None, id(w_basis[0])) if G == 1 else None
         ctx.layout = (packed[0] is not None, packed[1] is not None)

@@ -2597,7 +2597,10 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
-    if (dw_direct(g, b)) {                          // direct depthwise kernels: no split-K on the data path, no position-major copies
+    pl->fwd_halo = halo_fwd(g, b) ? 1 : 0;
+    pl->bwd_weight_halo = halo_bwd_weight(g, b) ? 1 : 0;
+    if (dw_direct(g, b)) {
+        pl->fwd_halo = pl->bwd_weight_halo = 0;                          // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
         pl->bwd_weight_splits = dw_weight_chunks(g);
         pl->x_pm_wanted = pl->dz_pm_wanted = 0;

@@ -307,7 +307,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
     wp, wd = _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, phases, x.device, st)
     x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
-    _launch("k_conv_fwd/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+    _launch(("k_conv_fwd_halo/o" if plan.fwd_halo else "k_conv_fwd/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
             lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),
                                      _ptr(x_pm), st), _executed_flops(geom, plan, "fwd") if x_pm is not None else None, _layer_tag(geom))
     return z, (wd, x_pm), geom, basis, plan
@@ -364,7 +364,7 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     dz_pm = _position_major(dz, 0, Ot) if (plan.dz_pm_wanted and xn is None) else None
     if need_w:
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
-        _launch("k_conv_bwd_weight/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+        _launch(("k_conv_bwd_weight_halo/o" if (plan.bwd_weight_halo and xn is None) else "k_conv_bwd_weight/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
                 lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
                                                 _ptr(dz_pm), st),
                 _executed_flops(geom, plan, "bwd_weight") if (x_pm is not None and dz_pm is not None) else None, _layer_tag(geom))

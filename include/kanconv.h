@@ -97,6 +97,8 @@ typedef struct KanPlan {
     int fwd_target, bwd_data_target, bwd_weight_target;   /* position-major launches: live steps per split (0 = n/a) */
     int x_pm_wanted, dz_pm_wanted;/* small padded planes: pass position-major copies (kan_position_major) of x / dz to
                                      unlock structural-zero tap skipping; optional, NULL keeps the image-major path */
+    int fwd_halo, bwd_weight_halo;/* informational: the forward / weight-gradient launch of this geometry uses the halo-tile kernel
+                                     (k_conv_fwd_halo / k_conv_bwd_weight_halo) -- profiling tools name their samples by it */
     long long packed_weight_bytes;    /* G*Kpad*Opad*4    : all groups, group j at j*Kpad*Opad floats */
     long long bwd_data_weight_bytes;  /* size of the bwd-data weight layout `wd`, all groups (equal blocks) */
     long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */

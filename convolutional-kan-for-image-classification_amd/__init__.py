@@ -21,3 +21,5 @@ from .train import train_step, train_model_generic   # noqa: F401,E402
 from .layers.gram_layers import GRAMKANConvNDLayer, GRAMKANConv2DLayer   # noqa: F401,E402
 from .layers.kan_conv import gramkan_conv   # noqa: F401,E402
 from .layers.conv_layers import KANConv3DLayer, FastKANConv3DLayer, ChebyKANConv3DLayer   # noqa: F401,E402
+from .layers.poly_layers import (BesselKANConv1DLayer, FibonacciKANConv1DLayer, GegenbauerKANConv1DLayer, HermiteKANConv1DLayer,   # noqa: F401,E402
+                                 LaguerreKANConv1DLayer, LucasKANConv1DLayer, TaylorKANConv1DLayer, FourierKANConv1DLayer)

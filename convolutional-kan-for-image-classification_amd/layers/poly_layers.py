@@ -30,11 +30,12 @@ import torch.nn as nn
 from .. import _lib as L
 from .. import ops
 from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm)
+from .conv_layers import _need_conv2d as _need_conv1d_or_2d
 
 
 def _need_conv2d(conv_class, ndim):
     if conv_class is not nn.Conv2d or ndim != 2:
-        raise NotImplementedError("the polynomial-family layers are built for 2-D only (1-D/3-D: SURVEY.md 8(f))")
+        raise NotImplementedError("this polynomial-family layer is built for 2-D only (1-D/3-D: SURVEY.md 8(f))")
 
 Coeffs = Tuple[float, float, float, List[Tuple[float, float, float]]]       # c0, a1, b1, [(A_k, B_k, C_k) for k = 2..]
 
@@ -54,7 +55,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
 
     def _setup(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
                base_activation, dropout, norm_kwargs, none_is_identity=True):
-        _need_conv2d(conv_class, ndim)
+        _need_conv1d_or_2d(conv_class, ndim)          # 1-D layers run the 2-D kernels on [B, C, 1, L] (_HipLayer)
         _check_groups(groups, input_dim, output_dim)
         if degree < self._min_degree:
             raise ValueError(self._min_degree_msg)
@@ -71,7 +72,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
                                                    bias=False) for _ in range(groups)])
         self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
         self.prelus = nn.ModuleList([nn.PReLU() for _ in range(groups)])
-        self.dropout = _dropout2d(dropout)
+        self.dropout = _dropout2d(dropout, ndim)
         for conv in self.base_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.poly_conv:
@@ -93,18 +94,18 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
     def forward(self, x, pool: bool = False):
         """`pool=True`: max_pool2d(layer(x), 2, 2) with the pooling inside the InstanceNorm+PReLU kernels (see KANConvNDLayer)."""
         spec = self.conv_spec()
-        wb = [m.weight for m in self.base_conv]
-        ws = [m.weight for m in self.poly_conv]
+        x = self._lift(x)
+        wb, ws = self._w(self.base_conv), self._w(self.poly_conv)
         prelus = [m.weight for m in self.prelus]
         if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
-            if pool and self.dropout is None:
+            if pool and self.dropout is None and self.ndim == 2:
                 ho, wo = spec.out_hw(x.shape[2], x.shape[3])
                 if ho % 2 == 0 and wo % 2 == 0:
                     return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
-            y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
+            y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
-            z = ops.kan_conv(spec, x, None, wb, ws)
+            z = self._lower(ops.kan_conv(spec, x, None, wb, ws))
             og = self.output_dim_group
             y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
@@ -134,6 +135,16 @@ class BesselKANConv2DLayer(BesselKANConvNDLayer):
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class BesselKANConv1DLayer(BesselKANConvNDLayer):
+    """bessel_kan_layers.py:192-200: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Fibonacci
 class FibonacciKANConvNDLayer(_RecurrenceKANConvNDLayer):
     """F_0 = 0, F_1 = 1, F_n = t F_{n-1} + F_{n-2}  (fibonacci_kan_layers.py compute_fibonacci_basis)."""
@@ -156,6 +167,16 @@ class FibonacciKANConv2DLayer(FibonacciKANConvNDLayer):
         super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class FibonacciKANConv1DLayer(FibonacciKANConvNDLayer):
+    """fibonacci_kan_layers.py:245-259: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Gegenbauer
@@ -184,6 +205,16 @@ class GegenbauerKANConv2DLayer(GegenbauerKANConvNDLayer):
                          dilation=dilation, ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class GegenbauerKANConv1DLayer(GegenbauerKANConvNDLayer):
+    """gegenbauer_kan_layers.py:227-241: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, alpha_param, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, alpha_param=alpha_param, groups=groups, padding=padding, stride=stride,
+                         dilation=dilation, ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Hermite
 class HermiteKANConvNDLayer(_RecurrenceKANConvNDLayer):
     """H_0 = 1, H_1 = 2t, H_n = 2t H_{n-1} - 2(n-1) H_{n-2}  (hermite_kan_layers.py:117-146; base_activation is called as given, :65)."""
@@ -204,6 +235,16 @@ class HermiteKANConv2DLayer(HermiteKANConvNDLayer):
         super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class HermiteKANConv1DLayer(HermiteKANConvNDLayer):
+    """hermite_kan_layers.py:185-193: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Laguerre
@@ -232,6 +273,16 @@ class LaguerreKANConv2DLayer(LaguerreKANConvNDLayer):
                          dilation=dilation, ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class LaguerreKANConv1DLayer(LaguerreKANConvNDLayer):
+    """laguerre_kan_layers.py:204-212: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, alpha, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, alpha=alpha, groups=groups, padding=padding, stride=stride,
+                         dilation=dilation, ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Lucas
 class LucasKANConvNDLayer(_RecurrenceKANConvNDLayer):
     """L_0 = 2, L_1 = t, L_n = t L_{n-1} + L_{n-2}  (lucas_kan_layers.py:140-174)."""
@@ -252,6 +303,16 @@ class LucasKANConv2DLayer(LucasKANConvNDLayer):
         super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class LucasKANConv1DLayer(LucasKANConvNDLayer):
+    """lucas_kan_layers.py:220-228: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Taylor
@@ -281,6 +342,16 @@ class TaylorKANConv2DLayer(TaylorKANConvNDLayer):
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class TaylorKANConv1DLayer(TaylorKANConvNDLayer):
+    """taylor_kan_layers.py:197-205: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Fourier
 class FourierKANConvNDLayer(_HipLayer):
     """fourier_kan_layers.py:63-212: y = Dropout(PReLU(norm(conv(act(x), W_base) + conv([cos(kx)]_k ++ [sin(kx)]_k, W_fourier)))),
@@ -289,7 +360,7 @@ class FourierKANConvNDLayer(_HipLayer):
     def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, grid_size, groups=1, padding=0, stride=1, dilation=1,
                  ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, smooth_initialization: bool = False, **norm_kwargs):
         super().__init__()
-        _need_conv2d(conv_class, ndim)
+        _need_conv1d_or_2d(conv_class, ndim)
         _check_groups(groups, input_dim, output_dim)
         if grid_size < 1:
             raise ValueError('grid_size must be at least 1')
@@ -308,7 +379,7 @@ class FourierKANConvNDLayer(_HipLayer):
                                                       bias=False) for _ in range(groups)])
         self.layer_norm = nn.ModuleList([norm_class(og, **_filter_norm_kwargs(norm_class, norm_kwargs)) for _ in range(groups)])
         self.prelus = nn.ModuleList([nn.PReLU() for _ in range(groups)])
-        self.dropout = _dropout2d(dropout)
+        self.dropout = _dropout2d(dropout, ndim)
         for conv in self.base_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.fourier_conv:
@@ -320,14 +391,14 @@ class FourierKANConvNDLayer(_HipLayer):
 
     def forward(self, x):
         spec = self.conv_spec()
-        wb = [m.weight for m in self.base_conv]
-        ws = [m.weight for m in self.fourier_conv]
+        x = self._lift(x)
+        wb, ws = self._w(self.base_conv), self._w(self.fourier_conv)
         prelus = [m.weight for m in self.prelus]
         if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
-            y = ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps)
+            y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
-            z = ops.kan_conv(spec, x, None, wb, ws)
+            z = self._lower(ops.kan_conv(spec, x, None, wb, ws))
             og = self.output_dim_group
             y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
@@ -341,6 +412,16 @@ class FourierKANConv2DLayer(FourierKANConvNDLayer):
         super().__init__(conv_class=nn.Conv2d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, grid_size=grid_size, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=2, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class FourierKANConv1DLayer(FourierKANConvNDLayer):
+    """fourier_kan_layers.py:233-241: the same layer on [B, C, L] (nn.Conv1d weights [O, C, k], InstanceNorm1d)."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, grid_size, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm1d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, grid_size=grid_size, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Jacobi

@@ -152,6 +152,11 @@ CASES_1D = [
     C("rbf", "1d_k5s2", 2, 4, 6, 1, 37, ndim=1, k=5, p=2, s=2),
     C("cheby", "1d_tiny", 2, 3, 4, 1, 20, ndim=1),
     C("cheby", "1d_deg4g2", 2, 4, 6, 1, 31, ndim=1, degree=4, groups=2, norm_kwargs={"affine": True}),
+    # 1-D shims of the recurrence families and FourierKAN (<family>_kan_layers.py: the ...KANConv1DLayer classes)
+    C("lucas", "1d_deg3", 2, 3, 4, 1, 20, ndim=1, degree=3),
+    C("gegenbauer", "1d_deg4s2g2", 3, 4, 6, 1, 33, ndim=1, degree=4, s=2, groups=2, act="silu", extra={"alpha_param": 1.5}, norm_kwargs={"affine": True}),
+    C("hermite", "1d_k5d2", 2, 5, 7, 1, 40, ndim=1, degree=3, k=5, p=4, d=2, xs=2.0),
+    C("fourier", "1d_g3", 2, 3, 4, 1, 24, ndim=1, degree=3),
 ]
 
 
@@ -216,10 +221,11 @@ def build_ref(c):
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
         if c["kind"] == "fourier":
-            return REF_LAYERS.FourierKANConv2DLayer(c["C"], c["O"], grid_size=c["degree"], **kw)
+            return (REF_LAYERS.FourierKANConv1DLayer if one_d else REF_LAYERS.FourierKANConv2DLayer)(c["C"], c["O"], grid_size=c["degree"], **kw)
         if c["kind"] == "legendre":
             kw.pop("base_activation", None)
-        return getattr(REF_LAYERS, POLY_FAMILIES[c["kind"]])(c["C"], c["O"], degree=c["degree"], **kw)
+        name = POLY_FAMILIES[c["kind"]].replace("2D", "1D") if one_d else POLY_FAMILIES[c["kind"]]
+        return getattr(REF_LAYERS, name)(c["C"], c["O"], degree=c["degree"], **kw)
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:
         kw["norm_layer"] = NORMS[c["norm"]]

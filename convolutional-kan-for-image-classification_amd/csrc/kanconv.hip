@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256) void k_position_major(const float* __restrict_
 //   1 / 2 : B-spline grid 5, order 3 (8 bases) + base branch SiLU / GELU          P = 9   (KANConv2DLayer defaults)
 //   3     : RBF, 8 centres + base branch SiLU                                     P = 9   (FastKANConv2DLayer defaults)
 //   4 / 5 : Chebyshev degree 4 / 3, no base branch                                P = 5 / 4
+//   9     : ReLU-KAN g = 5, k = 3 (8 planes) + base branch SiLU, phases in device memory  P = 9   (halo kernels only)
 __host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6) ? 5 : (fast == 5 || fast == 7) ? 4 : fast == 8 ? 6 : 9; }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
@@ -470,6 +471,23 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
         for (int k = 1; k < NB; ++k) {
             col[(1 + k) * ld] = inb ? Tc : 0.f;
             if (k + 1 < NB) { const float Tn = (bs.tab[3 * k] * t + bs.tab[3 * k + 1]) * Tc + bs.tab[3 * k + 2] * Tm; Tm = Tc; Tc = Tn; }
+        }
+        return;
+    }
+    if (KIND == KAN_BASIS_RELU && FAST == 9) {
+        // ReLU-KAN defaults (relu_kan_layers.py:118-136: g = 5, k = 3 => 8 planes, SiLU base branch, P = 9): the per-channel phases come
+        // from device memory (16 loads; the lanes of a wave mostly share the channel).  bs.order selects value / d phase_low / d phase_high
+        // as in kan_planes<KAN_BASIS_RELU> (uniform branch).  Used by the halo kernels, where expansions are rare.
+        const float* lo = bs.ctab + (size_t)(inb ? c : 0) * 16;
+        const float r = bs.p0;
+        const int mode = bs.order;
+        col[0] = (inb && mode == 0) ? silu_fast(xa) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(lo[8 + j] - xb, 0.f);
+            const float q = x1 * x2 * r, q2 = 2.0f * q * r;
+            const float v = mode == 0 ? q * q : mode == 1 ? -(q2 * x2) : q2 * x1;
+            col[(1 + j) * ld] = inb ? v : 0.f;
         }
         return;
     }
@@ -754,7 +772,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
     const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, DevBasis bs, int Opad,
     int n_pairs, int pairs_per_split, long long slab_elems, unsigned x_bytes, int tiles_o) {
     constexpr int TO = WO * 64, TP = 128, NT = WO * 2 * 64, NW = WO * 2, P = fast_planes(FAST), KC = 2 * P, T = 9;
-    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : KAN_BASIS_BSPLINE;
+    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : FAST == 9 ? KAN_BASIS_RELU : KAN_BASIS_BSPLINE;
     constexpr int HW_ = W + 2, HIMG = (R + 2) * HW_, HALO = NIMG * HIMG;          // cells per plane
     constexpr int RPI = 256 / TO, NQ = (KC + RPI - 1) / RPI;
     static_assert(NIMG * R * W == TP && HALO % 2 == 0, "tile shape");
@@ -781,7 +799,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
     const int b0 = px_tile0 / HoWo, h0 = (px_tile0 - b0 * HoWo) / W;
     // cells this thread expands every channel pair (fixed): cell -> (channel of the pair, image, halo row, halo column)
     constexpr int NCELL = 2 * HALO, CPT = (NCELL + NT - 1) / NT;
-    int c_src[CPT], c_dst[CPT]; unsigned c_ok = 0;                          // x element offset (without channel) / sH offset
+    int c_src[CPT], c_dst[CPT], c_ch[CPT]; unsigned c_ok = 0;               // x element offset (without channel) / sH offset / channel of the pair
 #pragma unroll
     for (int k = 0; k < CPT; ++k) {
         const int idx = tid + k * NT;
@@ -791,6 +809,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
         const bool ok = idx < NCELL && b < g.B && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)W;
         c_src[k] = b * (int)g.xbs + ch * HW + h * W + w;
         c_dst[k] = ch * (P * HALO) + cell;
+        c_ch[k] = ch;
         c_ok |= (ok ? 1u : 0u) << k;
     }
     const kan_rsrc x_rs = make_rsrc(x, x_bytes);
@@ -844,7 +863,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
         __syncthreads();                                     // all waves have finished reading the previous pair's halo
 #pragma unroll
         for (int k = 0; k < CPT; ++k)
-            if ((c_ok >> k) & 1u) stage_unit<KIND, FAST>(bs, sTab, true, xv[k], xv[k], sH + c_dst[k], HALO, sDump + tid);
+            if ((c_ok >> k) & 1u) stage_unit<KIND, FAST>(bs, sTab, true, xv[k], xv[k], sH + c_dst[k], HALO, sDump + tid, 2 * cp + c_ch[k]);
         // ---- nine taps: one weight step each
 #pragma unroll 1
         for (int tap = 0; tap < T; ++tap) {
@@ -1529,7 +1548,7 @@ template <int FAST, int W, int R, int NIMG>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
     const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dwp, DevGeom g, DevBasis bs, int Krows, int Opad,
     int n_bands, int bands_per_split, long long slab_elems, unsigned x_bytes, unsigned dz_bytes, int tiles_o) {
-    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : KAN_BASIS_BSPLINE;
+    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : FAST == 9 ? KAN_BASIS_RELU : KAN_BASIS_BSPLINE;
     constexpr int P = fast_planes(FAST), T = 9, PT = P * T;
     constexpr int TR = 128, TO = 128, NT = 256, KPX = 16;
     constexpr int HWc = W + 2, HIMG = (R + 2) * HWc, CELLS = NIMG * HIMG;        // a band is NIMG images x R rows (NIMG > 1: whole images)
@@ -1562,7 +1581,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
     float* const dump = sH + CELLS;                           // a pad word of plane 0 that no read touches
 
     // ---- expansion units of this thread (fixed): unit -> (channel of the tile, halo row, column)
-    int u_src[SLOTS], u_dst[SLOTS], u_hr[SLOTS]; unsigned u_ok = 0;
+    int u_src[SLOTS], u_dst[SLOTS], u_hr[SLOTS], u_ch[SLOTS]; unsigned u_ok = 0;
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int idx = tid + k * NT;
@@ -1570,7 +1589,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
         const int ch = idx / UPC, ri = idx - ch * UPC, img = ri / UPI, rc = ri - img * UPI, hr = rc / W, col = rc - hr * W;
         u_src[k] = (c0 + ch) * HW + img * (int)g.xbs + (hr - 1) * W + col;    // + image / band part per band
         u_dst[k] = ch * (P * PS) + img * HIMG + hr * HWc + col + 1;
-        u_hr[k] = hr - 1;
+        u_hr[k] = hr - 1; u_ch[k] = c0 + ch;
         u_ok |= ((idx < NU && c0 + ch < g.C) ? 1u : 0u) << k;
     }
     const kan_rsrc x_rs = make_rsrc(x, x_bytes), dz_rs = make_rsrc(dz, dz_bytes);
@@ -1622,7 +1641,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
     };
     auto expand = [&](int k, int hb) {
         if ((u_ok >> k) & 1u)
-            stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> k) & 1u, xv[k], xv[k], sH + hb * HB + u_dst[k], PS, dump);
+            stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> k) & 1u, xv[k], xv[k], sH + hb * HB + u_dst[k], PS, dump, u_ch[k]);
     };
 
     f32x16 acc[2][2];
@@ -2386,7 +2405,7 @@ bool big_tiles(const KanBasis* b, const KanPlan& pl) {
 bool halo_fwd(const KanGeom* g, const KanBasis* b) {
     const bool off = tuning_off("KAN_HALO");
     const int f = fast_variant(b);
-    if (off || !(f == 1 || f == 2 || f == 5 || f == 6)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3
+    if (off || !(f == 1 || f == 2 || f == 5 || f == 6 || f == 9)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3, ReLU-KAN defaults
     if (b->kind == KAN_BASIS_POLY && b->order == 0) return false;          // order 0 = basis on a second, pre-normalised tensor (LegendreKAN): tap-major kernel
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
     if ((g->C & 1) || g->O % 128 != 0) return false;
@@ -2506,7 +2525,7 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
 // CHANNEL-major: row = (c*T + tap)*P + p (kan_unpack_wgrad follows).
 bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
     const int f = fast_variant(b);
-    if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2)) return false;
+    if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2 || f == 9)) return false;
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
     if (round_up(g->O, 64) % 128 != 0 || g->C > 65535 / 81) return false;
     if (g->H != g->W) return false;
@@ -2634,6 +2653,7 @@ int fast_variant(const KanBasis* b) {
     if (b->kind == KAN_BASIS_RBF && b->act == KAN_ACT_SILU && (b->n_basis == 8 || b->n_basis == 5)) return b->n_basis == 8 ? 3 : 8;
     if (b->kind == KAN_BASIS_CHEBY && b->act == KAN_ACT_NONE) return b->n_basis == 5 ? 4 : b->n_basis == 4 ? 5 : 0;
     if (b->kind == KAN_BASIS_POLY && b->act != KAN_ACT_NONE) return b->n_basis == 4 ? 6 : b->n_basis == 3 ? 7 : 0;
+    if (b->kind == KAN_BASIS_RELU && b->act == KAN_ACT_SILU && b->n_basis == 8) return 9;      // halo kernels only
     return 0;
 }
 
@@ -2925,6 +2945,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         else if (c.TO == 128 && fv == 2) KAN_HALO_SHAPE(2, 2);
         else if (c.TO == 128 && fv == 5) KAN_HALO_SHAPE(5, 2);
         else if (c.TO == 128 && fv == 6) KAN_HALO_SHAPE(6, 2);
+        else if (c.TO == 128 && fv == 9) KAN_HALO_SHAPE(9, 2);
         else return fail("internal: no halo forward kernel for this basis / tile");
 #undef KAN_HALO_SHAPE
 #undef KAN_HALO
@@ -3086,6 +3107,9 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
         if (fv == 1 && g->W == 16) KAN_BWH(1, 16, 4, 1);
         else if (fv == 1 && g->W == 8) KAN_BWH(1, 8, 8, 1);
         else if (fv == 1) KAN_BWH(1, 4, 4, 2);
+        else if (fv == 9 && g->W == 16) KAN_BWH(9, 16, 4, 1);
+        else if (fv == 9 && g->W == 8) KAN_BWH(9, 8, 8, 1);
+        else if (fv == 9) KAN_BWH(9, 4, 4, 2);
         else if (g->W == 16) KAN_BWH(2, 16, 4, 1);
         else if (g->W == 8) KAN_BWH(2, 8, 8, 1);
         else KAN_BWH(2, 4, 4, 2);

@@ -218,3 +218,20 @@ def test_random_3d_vs_oracle(seed, gpu_lib):
     cfg = _cfg(kind, C, O, k=k, s=s_, p=p, d=d, groups=G, degree=3, ndim=3, act="gelu" if kind == "bspline" else "silu")
     x = torch.randn(B, C, D, H, W) * (1.0 + (seed % 2))
     _check(layer, cfg, x, dict(kind=kind, C=C, O=O, G=G, D=D, H=H, W=W, k=k, s=s_, d=d, p=p, B=B))
+
+
+@pytest.mark.parametrize("H,G,B", [(16, 1, 3), (8, 1, 5), (8, 2, 2), (4, 1, 6), (32, 1, 1)])
+def test_relukan_halo_kernels_vs_oracle(H, G, B, gpu_lib):
+    """ReLU-KAN defaults (g = 5, k = 3, SiLU) on the shapes that take the halo forward / halo weight-gradient kernels (compile-time
+    spec 9: per-channel phases read from device memory inside the halo expansion), forward, input gradient, weight gradients and
+    the phase gradients (weight-gradient kernel on the phase-derivative planes), against the oracle."""
+    torch.manual_seed(100 + H + G)
+    C, O = 6 * G, 128 * G
+    layer = K.CONV_KAN_FACTORY["ReLUKAN"](C, O, 3, groups=G, base_activation=torch.nn.SiLU)     # SiLU: what VGGKAN hands the factory (kan_vgg.py:316)
+    from convkan_amd import ops
+    geom, basis, plan = ops._plan_cached(layer.conv_spec(), B, C // G, H, H, O // G, C, O)
+    assert plan.fwd_halo == (1 if C // G % 2 == 0 else 0) and plan.bwd_weight_halo == (1 if H in (4, 8, 16) else 0), "shape does not reach the halo kernels"
+    with torch.no_grad():
+        layer.phase_low.add_(0.06 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.06 * torch.randn_like(layer.phase_high))
+    cfg = _cfg("relu", C, O, k=3, s=1, p=1, d=1, groups=G, degree=3, extra={}, act="silu")
+    _check(layer, cfg, torch.randn(B, C, H, H) * 1.5, dict(fam="ReLUKAN", C=C, O=O, G=G, H=H, W=H, B=B, affine=False))

@@ -423,7 +423,8 @@ __global__ __launch_bounds__(256) void k_position_major(const float* __restrict_
 //   3     : RBF, 8 centres + base branch SiLU                                     P = 9   (FastKANConv2DLayer defaults)
 //   4 / 5 : Chebyshev degree 4 / 3, no base branch                                P = 5 / 4
 //   9     : ReLU-KAN g = 5, k = 3 (8 planes) + base branch SiLU, phases in device memory  P = 9   (halo kernels only)
-__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6) ? 5 : (fast == 5 || fast == 7) ? 4 : fast == 8 ? 6 : 9; }
+//   10    : GRAM-KAN degree 3 (4 planes) + base branch, SiLU, coefficients in device memory  P = 5   (halo kernels only)
+__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6 || fast == 10) ? 5 : (fast == 5 || fast == 7) ? 4 : fast == 8 ? 6 : 9; }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
 template <int KIND, int FAST>
@@ -488,6 +489,30 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
             const float q = x1 * x2 * r, q2 = 2.0f * q * r;
             const float v = mode == 0 ? q * q : mode == 1 ? -(q2 * x2) : q2 * x1;
             col[(1 + j) * ld] = inb ? v : 0.f;
+        }
+        return;
+    }
+    if (KIND == KAN_BASIS_GRAM && FAST == 10) {
+        // GRAM-KAN degree 3 with SiLU (gram_kan_layers.py:150-182): planes act(P_k(tanh x)), P_0 = 1, P_1 = t, P_k = t P_{k-1} - c_k P_{k-2},
+        // c_k from device memory (layer-global); bs.order = m >= 1 selects the derivative w.r.t. c_{m+1} (act'(P_k) dP_k/dc), base plane
+        // zero, as kan_planes<KAN_BASIS_GRAM>.  tanh and SiLU through hardware exp2 / rcp.  P = 5.  Halo kernels only.
+        const float* cf = bs.ctab;
+        const int mode = bs.order;
+        const float e = __builtin_amdgcn_exp2f(fminf(xb, 40.f) * 2.88539008177792681472f);
+        const float t = (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+        col[0] = (inb && mode == 0) ? silu_fast(xa) : 0.f;
+        float Pm = 1.f, Pc = t, Qm = 0.f, Qc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float Pk = k == 0 ? 1.f : Pc, Qk = k == 0 ? 0.f : Qc;
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(Pk * -1.44269504088896340736f));
+            const float v = mode == 0 ? Pk * sg : sg * (1.0f + Pk * (1.0f - sg)) * Qk;
+            col[(1 + k) * ld] = inb ? v : 0.f;
+            if (k >= 1 && k + 1 < 4) {
+                const float ck = cf[k + 1];
+                const float Pn = t * Pc - ck * Pm, Qn = t * Qc - ck * Qm - (k + 1 == mode + 1 ? Pm : 0.f);
+                Pm = Pc; Pc = Pn; Qm = Qc; Qc = Qn;
+            }
         }
         return;
     }
@@ -772,7 +797,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
     const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, DevBasis bs, int Opad,
     int n_pairs, int pairs_per_split, long long slab_elems, unsigned x_bytes, int tiles_o) {
     constexpr int TO = WO * 64, TP = 128, NT = WO * 2 * 64, NW = WO * 2, P = fast_planes(FAST), KC = 2 * P, T = 9;
-    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : FAST == 9 ? KAN_BASIS_RELU : KAN_BASIS_BSPLINE;
+    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : FAST == 9 ? KAN_BASIS_RELU : FAST == 10 ? KAN_BASIS_GRAM : KAN_BASIS_BSPLINE;
     constexpr int HW_ = W + 2, HIMG = (R + 2) * HW_, HALO = NIMG * HIMG;          // cells per plane
     constexpr int RPI = 256 / TO, NQ = (KC + RPI - 1) / RPI;
     static_assert(NIMG * R * W == TP && HALO % 2 == 0, "tile shape");
@@ -1548,7 +1573,7 @@ template <int FAST, int W, int R, int NIMG>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
     const float* __restrict__ dz, const float* __restrict__ x, float* __restrict__ dwp, DevGeom g, DevBasis bs, int Krows, int Opad,
     int n_bands, int bands_per_split, long long slab_elems, unsigned x_bytes, unsigned dz_bytes, int tiles_o) {
-    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : FAST == 9 ? KAN_BASIS_RELU : KAN_BASIS_BSPLINE;
+    constexpr int KIND = (FAST == 4 || FAST == 5) ? KAN_BASIS_CHEBY : (FAST == 6 || FAST == 7) ? KAN_BASIS_POLY : FAST == 9 ? KAN_BASIS_RELU : FAST == 10 ? KAN_BASIS_GRAM : KAN_BASIS_BSPLINE;
     constexpr int P = fast_planes(FAST), T = 9, PT = P * T;
     constexpr int TR = 128, TO = 128, NT = 256, KPX = 16;
     constexpr int HWc = W + 2, HIMG = (R + 2) * HWc, CELLS = NIMG * HIMG;        // a band is NIMG images x R rows (NIMG > 1: whole images)
@@ -2405,7 +2430,7 @@ bool big_tiles(const KanBasis* b, const KanPlan& pl) {
 bool halo_fwd(const KanGeom* g, const KanBasis* b) {
     const bool off = tuning_off("KAN_HALO");
     const int f = fast_variant(b);
-    if (off || !(f == 1 || f == 2 || f == 5 || f == 6 || f == 9)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3, ReLU-KAN defaults
+    if (off || !(f == 1 || f == 2 || f == 5 || f == 6 || f == 9 || f == 10)) return false;     // B-spline defaults, ChebyKAN degree 3, recurrence families degree 3, ReLU-KAN / GRAM-KAN defaults
     if (b->kind == KAN_BASIS_POLY && b->order == 0) return false;          // order 0 = basis on a second, pre-normalised tensor (LegendreKAN): tap-major kernel
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
     if ((g->C & 1) || g->O % 128 != 0) return false;
@@ -2525,9 +2550,9 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
 // CHANNEL-major: row = (c*T + tap)*P + p (kan_unpack_wgrad follows).
 bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
     const int f = fast_variant(b);
-    if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2 || f == 9)) return false;
+    if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2 || f == 9 || f == 10)) return false;
     if (g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->dh != 1 || g->dw != 1 || g->ph != 1 || g->pw != 1) return false;
-    if (round_up(g->O, 64) % 128 != 0 || g->C > 65535 / 81) return false;
+    if (round_up(g->O, 64) % 128 != 0 || g->C > 65535 / 81) return false;      // (row index = (c*9 + tap)*P + p stays far below 2^31)
     if (g->H != g->W) return false;
     // 4x4 planes: two images per band, dense (31 % of the products multiply padding).  The position-major tap-skipping launch
     // wins where it has enough row tiles to balance its unequal taps (measured: 512 -> 512 142 TFLOP/s dense-equivalent against
@@ -2654,6 +2679,7 @@ int fast_variant(const KanBasis* b) {
     if (b->kind == KAN_BASIS_CHEBY && b->act == KAN_ACT_NONE) return b->n_basis == 5 ? 4 : b->n_basis == 4 ? 5 : 0;
     if (b->kind == KAN_BASIS_POLY && b->act != KAN_ACT_NONE) return b->n_basis == 4 ? 6 : b->n_basis == 3 ? 7 : 0;
     if (b->kind == KAN_BASIS_RELU && b->act == KAN_ACT_SILU && b->n_basis == 8) return 9;      // halo kernels only
+    if (b->kind == KAN_BASIS_GRAM && b->act == KAN_ACT_SILU && b->n_basis == 4) return 10;     // halo kernels only
     return 0;
 }
 
@@ -2946,6 +2972,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         else if (c.TO == 128 && fv == 5) KAN_HALO_SHAPE(5, 2);
         else if (c.TO == 128 && fv == 6) KAN_HALO_SHAPE(6, 2);
         else if (c.TO == 128 && fv == 9) KAN_HALO_SHAPE(9, 2);
+        else if (c.TO == 128 && fv == 10) KAN_HALO_SHAPE(10, 2);
         else return fail("internal: no halo forward kernel for this basis / tile");
 #undef KAN_HALO_SHAPE
 #undef KAN_HALO
@@ -3110,6 +3137,9 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
         else if (fv == 9 && g->W == 16) KAN_BWH(9, 16, 4, 1);
         else if (fv == 9 && g->W == 8) KAN_BWH(9, 8, 8, 1);
         else if (fv == 9) KAN_BWH(9, 4, 4, 2);
+        else if (fv == 10 && g->W == 16) KAN_BWH(10, 16, 4, 1);
+        else if (fv == 10 && g->W == 8) KAN_BWH(10, 8, 8, 1);
+        else if (fv == 10) KAN_BWH(10, 4, 4, 2);
         else if (g->W == 16) KAN_BWH(2, 16, 4, 1);
         else if (g->W == 8) KAN_BWH(2, 8, 8, 1);
         else KAN_BWH(2, 4, 4, 2);

@@ -235,3 +235,19 @@ def test_relukan_halo_kernels_vs_oracle(H, G, B, gpu_lib):
         layer.phase_low.add_(0.06 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.06 * torch.randn_like(layer.phase_high))
     cfg = _cfg("relu", C, O, k=3, s=1, p=1, d=1, groups=G, degree=3, extra={}, act="silu")
     _check(layer, cfg, torch.randn(B, C, H, H) * 1.5, dict(fam="ReLUKAN", C=C, O=O, G=G, H=H, W=H, B=B, affine=False))
+
+
+@pytest.mark.parametrize("H,G,B", [(16, 1, 3), (8, 2, 2), (4, 1, 6), (32, 1, 1)])
+def test_gramkan_halo_kernels_vs_oracle(H, G, B, gpu_lib):
+    """GRAM-KAN defaults (degree 3, SiLU) on the halo-kernel shapes (compile-time spec 10: recurrence coefficients read from device
+    memory inside the halo expansion), including the beta_weights gradient (weight-gradient kernel on the coefficient-derivative planes)."""
+    torch.manual_seed(200 + H + G)
+    C, O = 6 * G, 128 * G
+    layer = K.CONV_KAN_FACTORY["GRAMKAN"](C, O, 3, groups=G)
+    from convkan_amd import ops
+    geom, basis, plan = ops._plan_cached(layer.conv_spec(), B, C // G, H, H, O // G, C, O)
+    assert plan.fwd_halo == 1 and plan.bwd_weight_halo == (1 if H in (4, 8, 16) else 0), "shape does not reach the halo kernels"
+    with torch.no_grad():
+        layer.beta_weights.normal_(0.0, 0.2)
+    cfg = _cfg("gram", C, O, k=3, s=1, p=1, d=1, groups=G, degree=3, extra={}, act="silu")
+    _check(layer, cfg, torch.randn(B, C, H, H) * 1.5, dict(fam="GRAMKAN", C=C, O=O, G=G, H=H, W=H, B=B, affine=False))

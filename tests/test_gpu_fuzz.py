@@ -79,12 +79,14 @@ def _check(layer, cfg, x, c):
     y = dev(xg)
     y.backward(go.cuda())
     torch.cuda.synchronize()
-    ho, wo = dev.conv_spec().out_hw(c["H"], c["W"])
-    scale = 8.0 if ho * wo <= 4 else 4.0 if c["G"] == c["C"] else 2.0
+    # every tensor is judged against the fp64 oracle: stated tolerance, or 4 x what the fp32 oracle itself achieves on that tensor
+    # where the case is ill-conditioned (InstanceNorm over 2x2 / near-constant / mostly-padding planes).  KAN_FUZZ_SCALE widens the
+    # stated part for exploration; the committed value is 1.
+    scale = float(__import__("os").environ.get("KAN_FUZZ_SCALE", "1"))
 
     def tol(base, a32, a64):
         return max(base * scale, 4.0 * relerr(a32, a64))
-    errs = {"y": (relerr(y, y32), tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx32), tol(TOL_DX, dx32, dx64))}
+    errs = {"y": (relerr(y, y64), tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx64), tol(TOL_DX, dx32, dx64))}
     scal_h, scal_r, scal_64 = [], [], []
     for name, p_ in dev.named_parameters():
         if name not in dw32:
@@ -92,10 +94,10 @@ def _check(layer, cfg, x, c):
         if p_.numel() == 1:                                       # per-group PReLU slopes: judged together (one scalar each)
             scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dw32[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
         else:
-            errs[name] = (relerr(p_.grad, dw32[name]), tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
+            errs[name] = (relerr(p_.grad, dw64[name]), tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
     if scal_h:
         a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
-        errs["prelus"] = (relerr(a, b), tol(2e-5, b, b64))
+        errs["prelus"] = (relerr(a, b64), tol(2e-5, b, b64))
     bad = {k_: v for k_, v in errs.items() if not v[0] <= v[1]}
     assert not bad, f"{c}: {bad}"
 

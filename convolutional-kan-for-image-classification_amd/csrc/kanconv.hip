@@ -19,6 +19,7 @@
 #include <cstring>
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 #include "kanconv.h"
 #include "kan_device.h"
 
@@ -1738,6 +1739,175 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
         }
 }
 
+// ============================================================================ position-major, expanded: small planes
+// On 4x4 / 2x2 planes a launch sees only B*16 / B*4 pixels against up to 85 MB of weights; the position-major launches of
+// the tap-major kernels (which skip the taps that read padding) ran at 0.49 - 0.55 matrix-pipe busy with 2.6 - 3.2 vector
+// instructions per MFMA: every (pixel, tap) pair re-expands its input value in every row tile, dz passes through registers.
+// Here the EXPANDED operand is materialised once per layer call in position-major order,
+//     e_pm[((c*HW + pos)*P + p)*B + b] = plane_p(x[b][c][pos])        (19 - 75 MB on the KAN-VGG layers, next to 85 MB of weights),
+// and the weight-gradient kernel below is DMA + MFMA only: both operands arrive by LDS-DMA in the XOR-swizzled [row][16 px]
+// layout of k_conv_bwd_weight_halo (16 images of one position are contiguous in e_pm and in dz_pm).
+template <int KIND, int FAST>
+__global__ __launch_bounds__(256) void k_expand_pm(const float* __restrict__ x, float* __restrict__ e_pm, DevBasis bs, int B, int CHW, int HW,
+                                                   long long bstride, float* __restrict__ dump) {
+    __shared__ float tile[32][33];
+    __shared__ float sTab[KAN_MAX_TABLE];
+    const int e0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int P = FAST ? fast_planes(FAST) : bs.P;
+    if (threadIdx.x < KAN_MAX_TABLE) sTab[threadIdx.x] = bs.tab[threadIdx.x];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int b = b0 + ty + 8 * i, e = e0 + tx;
+        tile[ty + 8 * i][tx] = (b < B && e < CHW) ? x[(size_t)b * bstride + e] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = e0 + ty + 8 * i, b = b0 + tx;
+        if (e < CHW && b < B) {
+            const float v = tile[tx][ty + 8 * i];
+            stage_unit<KIND, FAST>(bs, sTab, true, v, v, e_pm + (size_t)e * P * B + b, B, dump + threadIdx.x, e / HW);
+        }
+    }
+}
+
+// dW tile = 128 rows of the tap-major flat K axis (one tap: C*P % 128 == 0 is required) x 128 outputs; a step = 16 images of one
+// output position; steps whose (position, tap) pair reads padding are skipped, split ranges are cut over live steps
+// (as k_conv_bwd_weight).  No staging code at all: per step and wave 16 DMA instructions, 32 ds_read_b32, 32 MFMA.
+__global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
+    const float* __restrict__ dz_pm, const float* __restrict__ e_pm, float* __restrict__ dwp, DevGeom g, int P, FastDiv divP, int Krows, int Opad,
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned dz_bytes, int tiles_o) {
+    constexpr int TR = 128, TO = 128, KPX = 16, ZB = KPX * TO, AB = KPX * TR;
+    __shared__ __attribute__((aligned(16))) float sA[2 * AB];
+    __shared__ __attribute__((aligned(16))) float sZ[2 * ZB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_r = wave >> 1, w_c = wave & 1, kh2 = lane >> 5;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, CP = g.C * P;
+    const BlockId blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int grp = blk.y / tiles_o;
+    const int k0 = blk.x * TR, o_tile0 = (blk.y - grp * tiles_o) * TO;
+    e_pm += (size_t)grp * g.C * HW * P * g.B;
+    dz_pm += (size_t)grp * g.O * HoWo * g.B;
+    dwp += (size_t)grp * Krows * Opad;
+    const int tap = k0 / CP, tr = tap / g.kw, tt = tap - tr * g.kw;          // the tile's tap (uniform)
+    const kan_rsrc e_rs = make_rsrc(e_pm, e_bytes), dz_rs = make_rsrc(dz_pm, dz_bytes);
+
+    // ---- DMA sources: wave w copies chunks 8 w .. 8 w + 7 of each operand (64 words = 4 rows x 16 images, XOR-swizzled)
+    unsigned aoff[8], zoff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int rl = 4 * (wave * 8 + j) + (lane >> 4), q = (lane & 15) ^ ((rl >> 1) & 15);
+        const int row = k0 + rl, rem = min(row, Krows - 1) - tap * CP, c = fastdiv(rem, divP), pp = rem - c * P;     // (computed unconditionally: no branch)
+        const unsigned va = (unsigned)(((c * HW) * P + pp) * g.B + q) * 4u, vz = (unsigned)((o_tile0 + rl) * HoWo * g.B + q) * 4u;
+        aoff[j] = row < Krows ? va : KAN_OOB;
+        zoff[j] = o_tile0 + rl < g.O ? vz : KAN_OOB;
+    }
+    // ---- operand read addresses: one per k-pair (swizzle), second 32-row / 32-output block and buffer as immediates
+    unsigned aA[KPX / 2], bB[KPX / 2];
+    {
+        const int rl = w_r * 64 + (lane & 31), ol = w_c * 64 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < KPX / 2; ++kk) {
+            aA[kk] = lds_addr(sA + rl * KPX + ((2 * kk + kh2) ^ ((rl >> 1) & 15)));
+            bB[kk] = lds_addr(sZ + ol * KPX + ((2 * kk + kh2) ^ ((ol >> 1) & 15)));
+        }
+    }
+    auto issue = [&](int ch, int buf) {
+        const int px = ch * KPX, pos = px / g.B, b0 = px - pos * g.B;      // 16 images b0.. of output position pos
+        const int ho = pos / g.Wo, wo = pos - ho * g.Wo;
+        const int inpos = (ho * g.sh - g.ph + tr * g.dh) * g.W + (wo * g.sw - g.pw + tt * g.dw);     // live steps only: inside the image
+        const int sa = __builtin_amdgcn_readfirstlane((inpos * P * g.B + b0) * 4), sz = __builtin_amdgcn_readfirstlane((pos * g.B + b0) * 4);
+        float* dA = sA + buf * AB + wave * (8 * 64);
+        float* dZ = sZ + buf * ZB + wave * (8 * 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(e_rs, (__attribute__((address_space(3))) void*)(dA + j * 64), 4, (int)aoff[j], sa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dZ + j * 64), 4, (int)zoff[j], sz, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // live positions of this tap, split ranges over live steps (k_conv_bwd_weight's scheme)
+    unsigned hwmask = 0;
+    for (int hw = 0; hw < HoWo; ++hw) hwmask |= (tap_alive_out(g, hw, tap) ? 1u : 0u) << hw;
+    auto seg = [&](int hw) { return (hw * g.B + KPX - 1) / KPX; };
+    int ch0, ch1;
+    {
+        const int L = live_step_count(hwmask, HoWo, n_chunks, seg);
+        const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));
+        if (blk.z >= S) { ch0 = ch1 = n_chunks; }
+        else {
+            ch0 = blk.z == 0 ? 0 : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * blk.z / S), seg);
+            ch1 = blk.z == S - 1 ? n_chunks : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * (blk.z + 1) / S), seg);
+        }
+    }
+    auto next_live = [&](int ch) -> int {
+        while (ch < ch1) {
+            const int hw = (ch * KPX) / g.B;
+            if ((hwmask >> hw) & 1u) return ch;
+            ch = ((hw + 1) * g.B) / KPX;                        // first step of the next position
+        }
+        return ch1;
+    };
+    int ch = next_live(ch0);
+    if (ch < ch1) issue(ch, 0);
+    // the buffer index is a literal in each copy of the step, so that every LDS offset is an immediate
+#define KAN_RD(CUR, n_, kk_) asm volatile("ds_read_b32 %0, %4 offset:%6\n\tds_read_b32 %1, %4 offset:%7\n\tds_read_b32 %2, %5 offset:%6\n\tds_read_b32 %3, %5 offset:%7" \
+                : "=&v"(fa[n_][0]), "=&v"(fa[n_][1]), "=&v"(fb[n_][0]), "=&v"(fb[n_][1]) : "v"(aA[kk_]), "v"(bB[kk_]), "n"((CUR) * AB * 4), "n"((CUR) * AB * 4 + 32 * KPX * 4) : "memory")
+#define KAN_PM_STEP(CUR)                                                                                     \
+    do {                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
+        __syncthreads();                                                                                     \
+        ch = next_live(ch + 1);                                                                              \
+        if (ch < ch1) issue(ch, (CUR) ^ 1);                                                                  \
+        float fa[2][2], fb[2][2];                                                                            \
+        KAN_RD(CUR, 0, 0);                                                                                   \
+        _Pragma("unroll") for (int kk = 0; kk < KPX / 2; ++kk) {                                             \
+            const int c_ = kk & 1, n_ = c_ ^ 1;                                                              \
+            if (kk + 1 < KPX / 2) {                                                                          \
+                KAN_RD(CUR, n_, kk + 1);                                                                     \
+                LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 4);                                    \
+            } else {                                                                                         \
+                LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 0);                                    \
+            }                                                                                                \
+            acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);                                             \
+            acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);                                             \
+            acc[1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[1][0]);                                             \
+            acc[1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[1][1]);                                             \
+        }                                                                                                    \
+    } while (0)
+    static_assert(AB == ZB, "one immediate serves both operands");
+    while (ch < ch1) {                                       // (a `break` between the two copies made hipcc spill 59 VGPRs)
+        KAN_PM_STEP(0);
+        if (ch < ch1) { KAN_PM_STEP(1); }
+    }
+#undef KAN_PM_STEP
+#undef KAN_RD
+
+    float* out = dwp + (size_t)blk.z * slab_elems;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = k0 + w_r * 64 + mi * 32 + mfma_row(r, lane);
+            if (row >= Krows) continue;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int o = o_tile0 + w_c * 64 + ni * 32 + (lane & 31);
+                out[(size_t)row * Opad + o] = acc[mi][ni][r];
+            }
+        }
+}
+
 // ============================================================================ depthwise (one input channel per group)
 // With C = 1 and O <= 2 per group (kan_mobilenetv2.py:253-255 replace_depthwise) the GEMM tiles above run at 1/128
 // utilisation; these direct kernels do the same arithmetic per output element instead.  They are HBM / VALU bound
@@ -2548,6 +2718,16 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
 // Halo weight-gradient kernel (k_conv_bwd_weight_halo): 3x3 / stride 1 / pad 1 layers of the default B-spline specs on square
 // 16x16 and 8x8 planes (KAN-VGG layers 1-3), whole 128-output tiles, single input tensor.  Its packed gradient is
 // CHANNEL-major: row = (c*T + tap)*P + p (kan_unpack_wgrad follows).
+// DMA-only position-major weight gradient on the expanded operand (k_conv_bwd_weight_pmdma): default B-spline specs, whole
+// 128-row tiles inside one tap, 16-image steps, 128-output tiles.
+bool pmdma_bwd_weight(const KanGeom* g, const KanBasis* b) {
+    const int f = fast_variant(b);
+    if (tuning_off("KAN_PMDMA") || !(f == 1 || f == 2)) return false;
+    if (!want_pix_major(g, b, PM_BWD_WEIGHT)) return false;
+    const int P = b->n_basis + (b->act != KAN_ACT_NONE);
+    return (g->C * P) % 128 == 0 && g->B % 16 == 0 && round_up(g->O, 64) % 128 == 0 &&
+           (long long)g->C * g->H * g->W * P * g->B * 4 < (1ll << 31);
+}
 bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
     const int f = fast_variant(b);
     if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2 || f == 9 || f == 10)) return false;
@@ -2557,7 +2737,7 @@ bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
     // 4x4 planes: two images per band, dense (31 % of the products multiply padding).  The position-major tap-skipping launch
     // wins where it has enough row tiles to balance its unequal taps (measured: 512 -> 512 142 TFLOP/s dense-equivalent against
     // 134 here; 256 -> 512 118 against 134), so it keeps the wide layers.
-    if (g->W == 4) return g->B % 2 == 0 && g->C <= 256;
+    if (g->W == 4) return !pmdma_bwd_weight(g, b) && g->B % 2 == 0 && g->C <= 256;
     return g->W == 16 || g->W == 8;
 }
 bool pm_bwd_weight(const KanGeom* g, const KanBasis* b) { return want_pix_major(g, b, PM_BWD_WEIGHT) && !halo_bwd_weight(g, b); }
@@ -2638,11 +2818,12 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_splits = fwd_cfg(g, b, *pl).splits;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
-    pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || pm_bwd_weight(g, b)) ? 1 : 0;
+    pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || (pm_bwd_weight(g, b) && !pmdma_bwd_weight(g, b))) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     pl->fwd_halo = halo_fwd(g, b) ? 1 : 0;
     pl->bwd_weight_halo = halo_bwd_weight(g, b) ? 1 : 0;
+    pl->e_pm_wanted = 0; pl->reserved = 0; pl->e_pm_elems = 0;
     if (dw_direct(g, b)) {
         pl->fwd_halo = pl->bwd_weight_halo = 0;                          // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
@@ -2656,6 +2837,10 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         const long long tiles_per_pos = (long long)ceil_div(g->B, fc.TP) * fc.tiles_o * G;
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
         pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * G, &pl->fwd_splits, fc.slots);
+    }
+    if (pmdma_bwd_weight(g, b)) {                // the weight gradient reads the expanded position-major copy (kan_position_major_expanded)
+        pl->e_pm_wanted = 1;
+        pl->e_pm_elems = (long long)G * g->C * g->H * g->W * pl->P * g->B + 256;       // + a pad the expansion kernel may scribble on
     }
     if (pm_bwd_weight(g, b)) {   // bwd-weight: one class per tap; a live position holds B/16 steps
         LiveClass cw[32]; BwCfg wc = bw_cfg(g, b, *pl);
@@ -3187,6 +3372,38 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
 #undef KAN_BW2
 #undef KAN_BW
     return launch_ok("conv_bwd_weight");
+}
+
+int kan_position_major_expanded(const float* x, float* e_pm, const KanGeom* g, const KanBasis* b, void* stream) {
+    KanPlan pl;
+    if (int rc = make_plan(g, b, &pl)) return rc;
+    if (!x || !e_pm) return fail("null tensor pointer");
+    if (!pl.e_pm_wanted) return fail("this geometry / basis does not use the expanded position-major copy (plan.e_pm_wanted)");
+    const int G = ngroups(g), CHW = G * g->C * g->H * g->W;
+    DevBasis db = dev_basis(b);
+    dim3 grid(ceil_div(CHW, 32), ceil_div(g->B, 32));
+    float* dump = e_pm + (pl.e_pm_elems - 256);
+    // (channel index handed to the basis functor = e / HW: only families with per-channel tables read it, none of which is offered here)
+    if (fast_variant(b) == 1) hipLaunchKernelGGL((k_expand_pm<KAN_BASIS_BSPLINE, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, e_pm, db, g->B, CHW, g->H * g->W, g->x_bstride, dump);
+    else hipLaunchKernelGGL((k_expand_pm<KAN_BASIS_BSPLINE, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, e_pm, db, g->B, CHW, g->H * g->W, g->x_bstride, dump);
+    return launch_ok("position_major_expanded");
+}
+
+int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* dwp, const KanGeom* g, const KanBasis* b, void* stream) {
+    KanPlan pl;
+    if (int rc = make_plan(g, b, &pl)) return rc;
+    if (!dz_pm || !e_pm || !dwp) return fail("null tensor pointer");
+    if (!pl.e_pm_wanted) return fail("this geometry / basis does not use the expanded position-major copy (plan.e_pm_wanted)");
+    const BwCfg c = bw_cfg(g, b, pl);
+    if (c.TR != 128 || c.TO != 128) return fail("internal: the expanded weight-gradient kernel is built for 128 x 128 tiles");
+    DevGeom dg = dev_geom(g);
+    dg.pix_major = 1;
+    if ((long long)c.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
+    dim3 grid(c.tiles_r, c.tiles_o * ngroups(g), pl.bwd_weight_splits);
+    hipLaunchKernelGGL(k_conv_bwd_weight_pmdma, grid, dim3(256), 0, (hipStream_t)stream, dz_pm, e_pm, dwp, dg, pl.P, make_fastdiv(pl.P), pl.K, pl.Opad, c.chunks,
+                       pl.bwd_weight_target, pl.bwd_weight_slab_elems, (unsigned)(((long long)pl.e_pm_elems - 256) * 4),
+                       (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o);
+    return launch_ok("conv_bwd_weight_expanded");
 }
 
 int kan_slab_reduce(const float* slabs, int n_slabs, long long slab_elems, float* out, int B, int Cn, int HW, long long bstride, void* stream) {

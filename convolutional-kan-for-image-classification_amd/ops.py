@@ -364,10 +364,18 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     dz_pm = _position_major(dz, 0, Ot) if (plan.dz_pm_wanted and xn is None) else None
     if need_w:
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
-        _launch(("k_conv_bwd_weight_halo/o" if (plan.bwd_weight_halo and xn is None) else "k_conv_bwd_weight/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
-                lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
-                                                _ptr(dz_pm), st),
-                _executed_flops(geom, plan, "bwd_weight") if (x_pm is not None and dz_pm is not None) else None, _layer_tag(geom))
+        if plan.e_pm_wanted and xn is None and dz_pm is not None:
+            # small padded planes: expanded position-major operand, DMA + MFMA weight gradient (kanconv.h)
+            e_pm = torch.empty(plan.e_pm_elems, device=x.device, dtype=torch.float32)
+            L.check(lib.kan_position_major_expanded(_ptr(x), _ptr(e_pm), C.byref(geom), C.byref(basis), st), "kan_position_major_expanded")
+            _launch("k_conv_bwd_weight_pmdma/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+                    lambda: lib.kan_conv_bwd_weight_expanded(_ptr(dz_pm), _ptr(e_pm), _ptr(dwp), C.byref(geom), C.byref(basis), st),
+                    _executed_flops(geom, plan, "bwd_weight"), _layer_tag(geom))
+        else:
+            _launch(("k_conv_bwd_weight_halo/o" if (plan.bwd_weight_halo and xn is None) else "k_conv_bwd_weight/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
+                    lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
+                                                    _ptr(dz_pm), st),
+                    _executed_flops(geom, plan, "bwd_weight") if (x_pm is not None and dz_pm is not None) else None, _layer_tag(geom))
         sb = _sink_for(wids[0], (Og, Cg, kh, kw), x.device) if (wids and G == 1 and spec.has_base) else None
         ss = _sink_for(wids[1], (Og, Cg * spec.n_basis, kh, kw), x.device) if (wids and G == 1) else None
         dwb = (sb.unsqueeze(0) if sb is not None else

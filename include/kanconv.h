@@ -97,6 +97,8 @@ typedef struct KanPlan {
     int fwd_target, bwd_data_target, bwd_weight_target;   /* position-major launches: live steps per split (0 = n/a) */
     int x_pm_wanted, dz_pm_wanted;/* small padded planes: pass position-major copies (kan_position_major) of x / dz to
                                      unlock structural-zero tap skipping; optional, NULL keeps the image-major path */
+    int e_pm_wanted, reserved;    /* the weight gradient of this geometry reads the EXPANDED position-major copy: build it with
+                                     kan_position_major_expanded (e_pm_elems floats) and call kan_conv_bwd_weight_expanded */
     int fwd_halo, bwd_weight_halo;/* informational: the forward / weight-gradient launch of this geometry uses the halo-tile kernel
                                      (k_conv_fwd_halo / k_conv_bwd_weight_halo) -- profiling tools name their samples by it */
     long long packed_weight_bytes;    /* G*Kpad*Opad*4    : all groups, group j at j*Kpad*Opad floats */
@@ -104,6 +106,7 @@ typedef struct KanPlan {
     long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */
     long long bwd_data_slab_elems;    /* B*x_bstride      : stride between dx slabs */
     long long bwd_weight_slab_elems;  /* G*K*Opad         : stride between dW slabs, group j at j*K*Opad inside a slab */
+    long long e_pm_elems;             /* floats of the expanded position-major copy (0 unless e_pm_wanted) */
 } KanPlan;
 
 const char* kan_version(void);
@@ -176,6 +179,15 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
  * = sum_pixels expanded[k][pixel] * dz[o][pixel], written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
 int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,
                         const KanGeom* geom, const KanBasis* basis, const float* x_pm, const float* dz_pm, void* stream);
+
+/* Small padded planes (plan.e_pm_wanted): the expanded operand in position-major order,
+ *   e_pm[((c*HW + pos)*P + p)*B + b] = plane_p(x[b][c][pos])        (c over all G*C channels; plan.e_pm_elems floats),
+ * materialised once per layer call -- on 4x4 / 2x2 planes it is 19 - 75 MB next to 85 MB of weights -- and the weight gradient on it:
+ * a DMA + MFMA kernel (both operands by LDS-DMA, the (position, tap) pairs that read padding skipped), same dwp layout and slab
+ * count as kan_conv_bwd_weight.  dz_pm = kan_position_major(dz).  Replaces the same reference lines as kan_conv_bwd_weight. */
+int kan_position_major_expanded(const float* x, float* e_pm, const KanGeom* geom, const KanBasis* basis, void* stream);
+int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* dwp,
+                                 const KanGeom* geom, const KanBasis* basis, void* stream);
 
 /* Sum the dwp slabs and scatter back to the reference layouts (inverse of kan_pack_weights; stacked [G,...] when
  * geom->groups = G).  dw_base may be NULL iff there is no base branch.  dwp is scratch: with >= 32 slabs the sum is

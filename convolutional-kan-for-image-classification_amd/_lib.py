@@ -31,7 +31,7 @@ class KanBasis(C.Structure):
 
 class KanPlan(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("P", "K", "IPC", "KC", "Kpad", "Opad", "fwd_splits", "bwd_data_splits", "bwd_weight_splits",
-                                          "fwd_target", "bwd_data_target", "bwd_weight_target", "x_pm_wanted", "dz_pm_wanted", "e_pm_wanted", "reserved", "fwd_halo", "bwd_weight_halo")] + \
+                                          "fwd_target", "bwd_data_target", "bwd_weight_target", "x_pm_wanted", "dz_pm_wanted", "bwd_weight_expanded", "reserved", "e_pm_wanted", "fwd_expanded", "fwd_halo", "bwd_weight_halo")] + \
                [(n, C.c_longlong) for n in ("packed_weight_bytes", "bwd_data_weight_bytes", "fwd_slab_elems", "bwd_data_slab_elems",
                                             "bwd_weight_slab_elems", "e_pm_elems")]
 
@@ -51,6 +51,7 @@ SIGNATURES = {
     "kan_conv_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _GP, _BP, _P, _P]),
     "kan_conv_bwd_weight": (_I, [_P, _P, _P, _P, _GP, _BP, _P, _P, _P]),
     "kan_position_major_expanded": (_I, [_P, _P, _GP, _BP, _P]),
+    "kan_conv_fwd_expanded": (_I, [_P, _P, _P, _GP, _BP, _P]),
     "kan_conv_bwd_weight_expanded": (_I, [_P, _P, _P, _GP, _BP, _P]),
     "kan_unpack_wgrad": (_I, [_P, _P, _P, _GP, _BP, _P]),
     "kan_slab_reduce": (_I, [_P, _I, _LL, _P, _I, _I, _I, _LL, _P]),

@@ -1772,6 +1772,115 @@ __global__ __launch_bounds__(256) void k_expand_pm(const float* __restrict__ x, 
     }
 }
 
+// Forward on the expanded operand: z[o][px] = sum_k wp[k][o] e[k][px], 128 outputs x 128 images of ONE output position, a step = one tap
+// of a channel pair (KC = 2 P rows: the tap-major packed layout with IPC = 2); both operands are straight LDS-DMA copies (16 B per
+// lane): KC x 128 weights, and KC rows of 128 consecutive images out of e_pm.  Dead (position, tap) pairs are skipped, split
+// ranges cut over live steps (as k_conv_fwd).
+template <int KC>
+__global__ __launch_bounds__(256, 4) void k_conv_fwd_pmdma(
+    const float* __restrict__ e_pm, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, int P, FastDiv divP, int Opad,
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned w_bytes, TilePerm perm, int tiles_o) {
+    constexpr int TO = 128, TP = 128, NT = 256, NQ = KC / 2;               // NQ 1-KiB wave copies per operand and step
+    __shared__ __attribute__((aligned(16))) float sW[2 * KC * TO];
+    __shared__ __attribute__((aligned(16))) float sE[2 * KC * TP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w_o = wave >> 1, w_p = wave & 1, kh2 = lane >> 5;
+    const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw;
+    const BlockId blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int grp = blk.y / tiles_o;
+    const int px_tile0 = (perm.n ? (int)perm.idx[blk.x] : blk.x) * TP, o_tile0 = (blk.y - grp * tiles_o) * TO;
+    const int pos = px_tile0 / g.B, b0 = px_tile0 - pos * g.B;             // the tile: images b0 .. b0 + 127 of output position pos
+    e_pm += (size_t)grp * g.C * HW * P * g.B;
+    z += (size_t)grp * g.O * HoWo;
+    wp += (size_t)grp * n_chunks * KC * Opad;
+    const kan_rsrc e_rs = make_rsrc(e_pm, e_bytes), w_rs = make_rsrc(wp, w_bytes);
+    const int ho = pos / g.Wo, wo = pos - ho * g.Wo;
+
+    // per-lane parts of the DMA sources (wave w issues copies q = w, w + 4, w + 8 of each operand: two rows per copy)
+    unsigned eoff[(NQ + 3) / 4];
+#pragma unroll
+    for (int j = 0; j < (NQ + 3) / 4; ++j) {
+        const int r = 2 * (j * 4 + wave) + (lane >> 5), cl = fastdiv(min(r, KC - 1), divP), pp = min(r, KC - 1) - cl * P;
+        eoff[j] = (unsigned)(((cl * HW) * P + pp) * g.B + (lane & 31) * 4) * 4u;
+    }
+    const unsigned woff = (unsigned)((lane >> 5) * Opad + (lane & 31) * 4) * 4u;
+    auto issue = [&](int ch, int buf) {
+        const int item = 2 * ch, tap = fastdiv(item, g.divC), c = item - tap * g.C;
+        const int r = fastdiv(tap, g.divKw), t = tap - r * g.kw;
+        const int inpos = (ho * g.sh - g.ph + r * g.dh) * g.W + (wo * g.sw - g.pw + t * g.dw);       // live steps only
+        const int se = __builtin_amdgcn_readfirstlane((((c * HW + inpos) * P) * g.B + b0) * 4);
+        const int sw = __builtin_amdgcn_readfirstlane((ch * KC * Opad + o_tile0) * 4);
+        float* dE = sE + buf * (KC * TP);
+        float* dW = sW + buf * (KC * TO);
+#pragma unroll
+        for (int j = 0; j < (NQ + 3) / 4; ++j) {
+            const int q = j * 4 + wave;
+            if (q < NQ) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(e_rs, (__attribute__((address_space(3))) void*)(dE + q * 256), 16, (int)eoff[j], se, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (__attribute__((address_space(3))) void*)(dW + q * 256), 16, (int)woff,
+                                                         sw + q * 2 * Opad * 4, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    unsigned tapmask = 0;
+    for (int tap = 0; tap < T; ++tap) tapmask |= (tap_alive_out(g, pos, tap) ? 1u : 0u) << tap;
+    auto seg = [&](int tap) { return (tap * g.C + 1) / 2; };
+    int ch0, ch1;
+    {
+        const int L = live_step_count(tapmask, T, n_chunks, seg);
+        const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));
+        if (blk.z >= S) { ch0 = ch1 = n_chunks; }
+        else {
+            ch0 = blk.z == 0 ? 0 : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * blk.z / S), seg);
+            ch1 = blk.z == S - 1 ? n_chunks : live_step_pos(tapmask, T, n_chunks, (int)((long long)L * (blk.z + 1) / S), seg);
+        }
+    }
+    auto next_live = [&](int ch) -> int {
+        while (ch < ch1) {
+            const int tap = (2 * ch) / g.C;
+            if ((tapmask >> tap) & 1u) return ch;
+            ch = ((tap + 1) * g.C) / 2;
+        }
+        return ch1;
+    };
+    int ch = next_live(ch0);
+    if (ch < ch1) issue(ch, 0);
+    const int ao = w_o * 64 + (lane & 31), bp = w_p * 64 + (lane & 31);
+    for (int cur = 0; ch < ch1; cur ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ch = next_live(ch + 1);
+        if (ch < ch1) issue(ch, cur ^ 1);
+        const unsigned aw = lds_addr(sW + cur * (KC * TO) + kh2 * TO + ao), ae = lds_addr(sE + cur * (KC * TP) + kh2 * TP + bp);
+        KAN_MFMA_STEP(KC / 2, aw, TO, ae, TP);
+    }
+
+    float* zs = z + (size_t)blk.z * slab_elems;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int b = b0 + w_p * 64 + ni * 32 + (lane & 31);
+        if (b >= g.B) continue;
+        float* zb = zs + (size_t)b * g.ybs + pos;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = o_tile0 + w_o * 64 + mi * 32 + mfma_row(r, lane);
+                if (o < g.O) zb[(size_t)o * HoWo] = acc[mi][ni][r];
+            }
+    }
+}
+
 // dW tile = 128 rows of the tap-major flat K axis (one tap: C*P % 128 == 0 is required) x 128 outputs; a step = 16 images of one
 // output position; steps whose (position, tap) pair reads padding are skipped, split ranges are cut over live steps
 // (as k_conv_bwd_weight).  No staging code at all: per step and wave 16 DMA instructions, 32 ds_read_b32, 32 MFMA.
@@ -2522,9 +2631,21 @@ DevGeom dev_geom(const KanGeom* g) {
 // bwd-data gain 40-60 % on 2x2 but nothing on 4x4 (their step latency, not the step count, sets the time there), so
 // they take the position-major path only up to 4 positions.
 enum { PM_FWD = 0, PM_BWD_DATA = 1, PM_BWD_WEIGHT = 2 };
+int fast_variant(const KanBasis* b);
+inline bool tuning_off(const char* name);
+inline bool tuning_on(const char* name);
+// The DMA-only forward on the expanded position-major operand (k_conv_fwd_pmdma): default B-spline specs (P = 9: 18-row steps),
+// channel pairs, 128-image and 128-output tiles.  Measured on 4x4 planes it LOSES to the dense halo forward (256->512: 0.76 vs 0.63 ms,
+// 512->512: 1.36 vs 1.24 -- 16 positions x 2 image tiles walk the 85 MB weight stream out of step), so the forward's position-major
+// limit stays at 4 positions (2x2 planes: 0.247 -> 0.211 ms); -DKAN_TUNING_KNOBS + KAN_PMDMA_FWD16=1 re-runs the experiment.
+bool pmdma_fwd_shape(const KanGeom* g, const KanBasis* b) {
+    const int f = fast_variant(b);
+    return !tuning_off("KAN_PMDMA_FWD") && (f == 1 || f == 2) && g->C % 2 == 0 && g->B % 128 == 0 && ((g->O + 63) / 64 * 64) % 128 == 0 &&
+           (long long)g->C * g->H * g->W * 9 * g->B * 4 < (1ll << 31);
+}
 bool want_pix_major(const KanGeom* g, const KanBasis* b, int which) {
     const int plane = which == PM_BWD_DATA ? g->H * g->W : g->Ho * g->Wo;
-    const int limit = which == PM_BWD_WEIGHT ? 16 : 4;
+    const int limit = which == PM_BWD_WEIGHT ? 16 : (which == PM_FWD && pmdma_fwd_shape(g, b) && tuning_on("KAN_PMDMA_FWD16")) ? 16 : 4;
     return b->kind != KAN_BASIS_RBF && plane <= limit && g->kh * g->kw <= 32 && (g->ph > 0 || g->pw > 0) && g->B >= 16;
 }
 
@@ -2582,6 +2703,15 @@ inline bool tuning_off(const char* name) {
 #ifdef KAN_TUNING_KNOBS
     const char* e = getenv(name);
     return e && atoi(e) == 0;
+#else
+    (void)name;
+    return false;
+#endif
+}
+inline bool tuning_on(const char* name) {              // opt-in experiments (NAME=1), same build flag
+#ifdef KAN_TUNING_KNOBS
+    const char* e = getenv(name);
+    return e && atoi(e) != 0;
 #else
     (void)name;
     return false;
@@ -2728,6 +2858,7 @@ bool pmdma_bwd_weight(const KanGeom* g, const KanBasis* b) {
     return (g->C * P) % 128 == 0 && g->B % 16 == 0 && round_up(g->O, 64) % 128 == 0 &&
            (long long)g->C * g->H * g->W * P * g->B * 4 < (1ll << 31);
 }
+bool pmdma_fwd(const KanGeom* g, const KanBasis* b) { return pmdma_fwd_shape(g, b) && want_pix_major(g, b, PM_FWD); }
 bool halo_bwd_weight(const KanGeom* g, const KanBasis* b) {
     const int f = fast_variant(b);
     if (tuning_off("KAN_HALO_BW") || !(f == 1 || f == 2 || f == 9 || f == 10)) return false;
@@ -2818,12 +2949,12 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_splits = fwd_cfg(g, b, *pl).splits;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
-    pl->x_pm_wanted = (want_pix_major(g, b, PM_FWD) || (pm_bwd_weight(g, b) && !pmdma_bwd_weight(g, b))) ? 1 : 0;
+    pl->x_pm_wanted = ((want_pix_major(g, b, PM_FWD) && !pmdma_fwd(g, b)) || (pm_bwd_weight(g, b) && !pmdma_bwd_weight(g, b))) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     pl->fwd_halo = halo_fwd(g, b) ? 1 : 0;
     pl->bwd_weight_halo = halo_bwd_weight(g, b) ? 1 : 0;
-    pl->e_pm_wanted = 0; pl->reserved = 0; pl->e_pm_elems = 0;
+    pl->e_pm_wanted = 0; pl->fwd_expanded = 0; pl->bwd_weight_expanded = 0; pl->reserved = 0; pl->e_pm_elems = 0;
     if (dw_direct(g, b)) {
         pl->fwd_halo = pl->bwd_weight_halo = 0;                          // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
@@ -2838,7 +2969,9 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         for (int hw = 0; hw < plane; ++hw) cls[hw] = LiveClass{tiles_per_pos, live_taps_out(g, hw) * ceil_div(g->C, pl->IPC)};
         pl->fwd_target = pick_target_steps(cls, plane, 8, 4.0 * g->B * g->O * g->Ho * g->Wo * G, &pl->fwd_splits, fc.slots);
     }
-    if (pmdma_bwd_weight(g, b)) {                // the weight gradient reads the expanded position-major copy (kan_position_major_expanded)
+    pl->fwd_expanded = pmdma_fwd(g, b) ? 1 : 0;
+    pl->bwd_weight_expanded = pmdma_bwd_weight(g, b) ? 1 : 0;
+    if (pl->bwd_weight_expanded || pl->fwd_expanded) {    // the expanded position-major copy (kan_position_major_expanded) feeds the forward / the weight gradient
         pl->e_pm_wanted = 1;
         pl->e_pm_elems = (long long)G * g->C * g->H * g->W * pl->P * g->B + 256;       // + a pad the expansion kernel may scribble on
     }
@@ -3389,11 +3522,35 @@ int kan_position_major_expanded(const float* x, float* e_pm, const KanGeom* g, c
     return launch_ok("position_major_expanded");
 }
 
+int kan_conv_fwd_expanded(const float* e_pm, const float* wp, float* z, const KanGeom* g, const KanBasis* b, void* stream) {
+    KanPlan pl;
+    if (int rc = make_plan(g, b, &pl)) return rc;
+    if (!e_pm || !wp || !z) return fail("null tensor pointer");
+    if (!pl.fwd_expanded) return fail("the forward of this geometry / basis does not read the expanded position-major copy (plan.fwd_expanded)");
+    const FwdCfg c = fwd_cfg(g, b, pl);
+    if (c.TO != 128 || c.TP != 128 || pl.KC != 18 || pl.IPC != 2) return fail("internal: the expanded forward kernel is built for 128 x 128 tiles and 18-row steps");
+    DevGeom dg = dev_geom(g);
+    dg.pix_major = 1;
+    TilePerm perm; perm.n = 0;
+    if (c.tiles_p <= PERM_MAX) {                             // weight of a pixel tile = its live work (as kan_conv_fwd)
+        int wts[PERM_MAX];
+        const int tpp = ceil_div(g->B, c.TP), cpt = ceil_div(g->C, pl.IPC);
+        for (int t = 0; t < c.tiles_p; ++t) wts[t] = live_taps_out(g, t / tpp) * cpt;
+        perm = balance_tiles(wts, c.tiles_p);
+    }
+    if ((long long)c.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
+    dim3 grid(c.tiles_p, c.tiles_o * ngroups(g), pl.fwd_splits);
+    hipLaunchKernelGGL((k_conv_fwd_pmdma<18>), grid, dim3(256), 0, (hipStream_t)stream, e_pm, wp, z, dg, pl.P, make_fastdiv(pl.P), pl.Opad, c.chunks,
+                       pl.fwd_target, pl.fwd_slab_elems, (unsigned)(((long long)pl.e_pm_elems - 256) * 4),
+                       (unsigned)((long long)pl.Kpad * pl.Opad * 4), perm, c.tiles_o);
+    return launch_ok("conv_fwd_expanded");
+}
+
 int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* dwp, const KanGeom* g, const KanBasis* b, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz_pm || !e_pm || !dwp) return fail("null tensor pointer");
-    if (!pl.e_pm_wanted) return fail("this geometry / basis does not use the expanded position-major copy (plan.e_pm_wanted)");
+    if (!pl.bwd_weight_expanded) return fail("the weight gradient of this geometry / basis does not read the expanded position-major copy (plan.bwd_weight_expanded)");
     const BwCfg c = bw_cfg(g, b, pl);
     if (c.TR != 128 || c.TO != 128) return fail("internal: the expanded weight-gradient kernel is built for 128 x 128 tiles");
     DevGeom dg = dev_geom(g);

@@ -306,11 +306,26 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     st = _stream(x)
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
     wp, wd = _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, phases, x.device, st)
+    if plan.fwd_expanded and xn is None and phases is None:
+        # small padded planes: the expanded position-major operand (kept for the weight gradient), DMA + MFMA forward
+        e_pm = _expand_pm(x, geom, basis, plan, st)
+        _launch("k_conv_fwd_pmdma/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
+                lambda: lib.kan_conv_fwd_expanded(_ptr(e_pm), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis), st),
+                _executed_flops(geom, plan, "fwd"), _layer_tag(geom))
+        # what the backward keeps: the expanded copy (its weight gradient reads it), or -- when that launch still runs the
+        # tap-major position-major kernel -- the plain copy it needs
+        return z, (wd, _position_major(x, 0, Ct) if plan.x_pm_wanted else e_pm), geom, basis, plan
     x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
     _launch(("k_conv_fwd_halo/o" if plan.fwd_halo else "k_conv_fwd/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
             lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),
                                      _ptr(x_pm), st), _executed_flops(geom, plan, "fwd") if x_pm is not None else None, _layer_tag(geom))
     return z, (wd, x_pm), geom, basis, plan
+
+
+def _expand_pm(x, geom, basis, plan, st):
+    e_pm = torch.empty(plan.e_pm_elems, device=x.device, dtype=torch.float32)
+    L.check(L.load().kan_position_major_expanded(_ptr(x), _ptr(e_pm), C.byref(geom), C.byref(basis), st), "kan_position_major_expanded")
+    return e_pm
 
 
 # --------------------------------------------------------------------------------------- gradient sinks (data parallel)
@@ -364,10 +379,9 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
     dz_pm = _position_major(dz, 0, Ot) if (plan.dz_pm_wanted and xn is None) else None
     if need_w:
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
-        if plan.e_pm_wanted and xn is None and dz_pm is not None:
+        if plan.bwd_weight_expanded and xn is None and dz_pm is not None:
             # small padded planes: expanded position-major operand, DMA + MFMA weight gradient (kanconv.h)
-            e_pm = torch.empty(plan.e_pm_elems, device=x.device, dtype=torch.float32)
-            L.check(lib.kan_position_major_expanded(_ptr(x), _ptr(e_pm), C.byref(geom), C.byref(basis), st), "kan_position_major_expanded")
+            e_pm = x_pm if (plan.fwd_expanded and not plan.x_pm_wanted and x_pm is not None and phases is None) else _expand_pm(x, geom, basis, plan, st)   # the forward's copy, if it kept one
             _launch("k_conv_bwd_weight_pmdma/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
                     lambda: lib.kan_conv_bwd_weight_expanded(_ptr(dz_pm), _ptr(e_pm), _ptr(dwp), C.byref(geom), C.byref(basis), st),
                     _executed_flops(geom, plan, "bwd_weight"), _layer_tag(geom))

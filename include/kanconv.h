@@ -97,8 +97,10 @@ typedef struct KanPlan {
     int fwd_target, bwd_data_target, bwd_weight_target;   /* position-major launches: live steps per split (0 = n/a) */
     int x_pm_wanted, dz_pm_wanted;/* small padded planes: pass position-major copies (kan_position_major) of x / dz to
                                      unlock structural-zero tap skipping; optional, NULL keeps the image-major path */
-    int e_pm_wanted, reserved;    /* the weight gradient of this geometry reads the EXPANDED position-major copy: build it with
-                                     kan_position_major_expanded (e_pm_elems floats) and call kan_conv_bwd_weight_expanded */
+    int bwd_weight_expanded, reserved;   /* the weight gradient reads the expanded copy (kan_conv_bwd_weight_expanded) */
+    int e_pm_wanted, fwd_expanded;/* small padded planes: the weight gradient (and, with fwd_expanded, the forward) reads the EXPANDED
+                                     position-major copy: build it with kan_position_major_expanded (e_pm_elems floats) and call
+                                     kan_conv_bwd_weight_expanded / kan_conv_fwd_expanded */
     int fwd_halo, bwd_weight_halo;/* informational: the forward / weight-gradient launch of this geometry uses the halo-tile kernel
                                      (k_conv_fwd_halo / k_conv_bwd_weight_halo) -- profiling tools name their samples by it */
     long long packed_weight_bytes;    /* G*Kpad*Opad*4    : all groups, group j at j*Kpad*Opad floats */
@@ -186,6 +188,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
  * a DMA + MFMA kernel (both operands by LDS-DMA, the (position, tap) pairs that read padding skipped), same dwp layout and slab
  * count as kan_conv_bwd_weight.  dz_pm = kan_position_major(dz).  Replaces the same reference lines as kan_conv_bwd_weight. */
 int kan_position_major_expanded(const float* x, float* e_pm, const KanGeom* geom, const KanBasis* basis, void* stream);
+int kan_conv_fwd_expanded(const float* e_pm, const float* wp, float* z, const KanGeom* geom, const KanBasis* basis, void* stream);   /* plan.fwd_expanded; z slabs as kan_conv_fwd */
 int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* dwp,
                                  const KanGeom* geom, const KanBasis* basis, void* stream);
 

@@ -36,6 +36,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
             os.close(fd)
             cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC", "-I", os.path.join(_ROOT, "include"),
                    "-I", os.path.join(_HERE, "csrc"), "-o", tmp] + SOURCES
+            if os.environ.get("KAN_BUILD_TUNING_KNOBS"):      # experiment builds only: the shipped library reads no environment variable
+                cmd.insert(1, "-DKAN_TUNING_KNOBS")
             if verbose:
                 print(" ".join(cmd))
             try:

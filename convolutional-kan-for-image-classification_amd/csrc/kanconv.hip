@@ -1779,7 +1779,7 @@ __global__ __launch_bounds__(256) void k_expand_pm(const float* __restrict__ x, 
 template <int KC>
 __global__ __launch_bounds__(256, 4) void k_conv_fwd_pmdma(
     const float* __restrict__ e_pm, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, int P, FastDiv divP, int Opad,
-    int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned w_bytes, TilePerm perm, int tiles_o) {
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned w_bytes, TilePerm perm, int tiles_o, int xcd) {
     constexpr int TO = 128, TP = 128, NT = 256, NQ = KC / 2;               // NQ 1-KiB wave copies per operand and step
     __shared__ __attribute__((aligned(16))) float sW[2 * KC * TO];
     __shared__ __attribute__((aligned(16))) float sE[2 * KC * TP];
@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_fwd_pmdma(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w_o = wave >> 1, w_p = wave & 1, kh2 = lane >> 5;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, T = g.kh * g.kw;
-    const BlockId blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const BlockId blk = xcd_block_order(xcd != 0);
     const int grp = blk.y / tiles_o;
     const int px_tile0 = (perm.n ? (int)perm.idx[blk.x] : blk.x) * TP, o_tile0 = (blk.y - grp * tiles_o) * TO;
     const int pos = px_tile0 / g.B, b0 = px_tile0 - pos * g.B;             // the tile: images b0 .. b0 + 127 of output position pos
@@ -3532,7 +3532,8 @@ int kan_conv_fwd_expanded(const float* e_pm, const float* wp, float* z, const Ka
     DevGeom dg = dev_geom(g);
     dg.pix_major = 1;
     TilePerm perm; perm.n = 0;
-    if (c.tiles_p <= PERM_MAX) {                             // weight of a pixel tile = its live work (as kan_conv_fwd)
+    const int xcd = tuning_on("KAN_PMDMA_XCD") ? 1 : 0;
+    if (c.tiles_p <= PERM_MAX && !xcd) {                     // weight of a pixel tile = its live work (as kan_conv_fwd)
         int wts[PERM_MAX];
         const int tpp = ceil_div(g->B, c.TP), cpt = ceil_div(g->C, pl.IPC);
         for (int t = 0; t < c.tiles_p; ++t) wts[t] = live_taps_out(g, t / tpp) * cpt;
@@ -3542,7 +3543,7 @@ int kan_conv_fwd_expanded(const float* e_pm, const float* wp, float* z, const Ka
     dim3 grid(c.tiles_p, c.tiles_o * ngroups(g), pl.fwd_splits);
     hipLaunchKernelGGL((k_conv_fwd_pmdma<18>), grid, dim3(256), 0, (hipStream_t)stream, e_pm, wp, z, dg, pl.P, make_fastdiv(pl.P), pl.Opad, c.chunks,
                        pl.fwd_target, pl.fwd_slab_elems, (unsigned)(((long long)pl.e_pm_elems - 256) * 4),
-                       (unsigned)((long long)pl.Kpad * pl.Opad * 4), perm, c.tiles_o);
+                       (unsigned)((long long)pl.Kpad * pl.Opad * 4), perm, c.tiles_o, xcd);
     return launch_ok("conv_fwd_expanded");
 }
 

@@ -55,7 +55,7 @@ def main():
         prof, ops.PROFILE = ops.PROFILE, None
         t = {}
         for smp in prof:
-            key = smp.name.split("/")[0].replace("k_conv_", "")
+            key = smp.name.split("/")[0].replace("k_conv_", "").replace("_halo", "").replace("_pmdma", "")
             t[key] = t.get(key, 0.0) + smp.start.elapsed_time(smp.end) / a.iters
         t_all_f = timed(lambda: ops._conv_forward(spec, x, None, wb, ws), a.iters)
         t_all_b = timed(lambda: ops._conv_backward(spec, x, None, packed, dz, li != 0, False, True), a.iters)

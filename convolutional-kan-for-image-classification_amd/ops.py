@@ -17,7 +17,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import threading
 import weakref
 from collections import OrderedDict
 from dataclasses import dataclass
@@ -219,18 +218,6 @@ class PackedWeights:
         self.cur, self.stamps = 0, None
 
 
-class _CallState(threading.local):
-    """(kept for API symmetry) set by the public entry points around Function.apply."""
-    no_grad = False
-
-
-_CALL = _CallState()
-
-
-def _records_no_graph(*tensors) -> bool:
-    return not torch.is_grad_enabled() or not any(t is not None and t.requires_grad for t in tensors)
-
-
 @lru_cache(maxsize=512)
 def _cacheable(plan_key) -> bool:
     geom, basis, _ = _plan_cached(*plan_key)
@@ -292,7 +279,7 @@ def _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, p
     return ent.wp, (ent.wd if need_dgrad else None)
 
 
-def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True, phases=None, cache_ok: bool = False):
+def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = True, phases=None):
     """Returns (z_slabs [S,B,O,Ho,Wo], (bwd-data weight layout or None, position-major x or None), geom, basis, plan)."""
     lib = L.load()
     B, Ct, H, W = x.shape
@@ -446,7 +433,7 @@ class _KanConv(torch.autograd.Function):
         w_base, w_basis = _split_weights(spec, weights)
         need_dgrad = bool(ctx.needs_input_grad[1] or (xn is not None and ctx.needs_input_grad[2]))
         with torch.cuda.device(x.device):
-            z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis, need_dgrad, cache_ok=_CALL.no_grad)
+            z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis, need_dgrad)
             z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
         ctx.spec, ctx.has_xn = spec, xn is not None
         ctx.layout = (packed[0] is not None, packed[1] is not None)
@@ -547,7 +534,7 @@ class _KanConvInPrelu(torch.autograd.Function):
             raise L.KanConvError("only scalar-slope PReLU (nn.PReLU()) is supported, as in kan_layers.py:182")
         need_dgrad = bool(ctx.needs_input_grad[5])
         with torch.cuda.device(x.device):
-            zs, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, need_dgrad, cache_ok=_CALL.no_grad)
+            zs, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, need_dgrad)
             S, B, Ot, Ho, Wo = zs.shape
             Og, HW = Ot // G, Ho * Wo
             mean = torch.empty(B * Ot, device=x.device, dtype=torch.float32)
@@ -661,11 +648,7 @@ class _InstanceNorm(torch.autograd.Function):
 def kan_conv(spec: ConvSpec, x: torch.Tensor, xn: Optional[torch.Tensor], w_base: Sequence[torch.Tensor],
              w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
-    _CALL.no_grad = _records_no_graph(x, xn, *ws)
-    try:
-        return _KanConv.apply(spec, x, xn, *ws)
-    finally:
-        _CALL.no_grad = False
+    return _KanConv.apply(spec, x, xn, *ws)
 
 
 def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_base: Sequence[torch.Tensor],
@@ -683,11 +666,7 @@ def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Te
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     aff = gammas is not None
     extra = (list(gammas) + list(betas) if aff else []) + (list(prelus) if prelus is not None else [])
-    _CALL.no_grad = _records_no_graph(x, *ws, *extra)
-    try:
-        return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), x, *ws, *extra)
-    finally:
-        _CALL.no_grad = False
+    return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), x, *ws, *extra)
 
 
 def instance_norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None, eps: float = 1e-5):

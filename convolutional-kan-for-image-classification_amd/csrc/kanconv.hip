@@ -1748,7 +1748,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_halo(
 // and the weight-gradient kernel below is DMA + MFMA only: both operands arrive by LDS-DMA in the XOR-swizzled [row][16 px]
 // layout of k_conv_bwd_weight_halo (16 images of one position are contiguous in e_pm and in dz_pm).
 template <int KIND, int FAST>
-__global__ __launch_bounds__(256) void k_expand_pm(const float* __restrict__ x, float* __restrict__ e_pm, DevBasis bs, int B, int CHW, int HW,
+__global__ __launch_bounds__(256) void k_expand_pm(const float* __restrict__ x, float* __restrict__ e_pm, DevBasis bs, int B, int CHW, int HW, int Cg,
                                                    long long bstride, float* __restrict__ dump) {
     __shared__ float tile[32][33];
     __shared__ float sTab[KAN_MAX_TABLE];
@@ -1767,7 +1767,7 @@ __global__ __launch_bounds__(256) void k_expand_pm(const float* __restrict__ x, 
         const int e = e0 + ty + 8 * i, b = b0 + tx;
         if (e < CHW && b < B) {
             const float v = tile[tx][ty + 8 * i];
-            stage_unit<KIND, FAST>(bs, sTab, true, v, v, e_pm + (size_t)e * P * B + b, B, dump + threadIdx.x, e / HW);
+            stage_unit<KIND, FAST>(bs, sTab, true, v, v, e_pm + (size_t)e * P * B + b, B, dump + threadIdx.x, (e / HW) % Cg);   // channel inside its group
         }
     }
 }
@@ -2640,7 +2640,7 @@ inline bool tuning_on(const char* name);
 // limit stays at 4 positions (2x2 planes: 0.247 -> 0.211 ms); -DKAN_TUNING_KNOBS + KAN_PMDMA_FWD16=1 re-runs the experiment.
 bool pmdma_fwd_shape(const KanGeom* g, const KanBasis* b) {
     const int f = fast_variant(b);
-    return !tuning_off("KAN_PMDMA_FWD") && (f == 1 || f == 2) && g->C % 2 == 0 && g->B % 128 == 0 && ((g->O + 63) / 64 * 64) % 128 == 0 &&
+    return !tuning_off("KAN_PMDMA_FWD") && (f == 1 || f == 2 || f == 9) && g->C % 2 == 0 && g->B % 128 == 0 && ((g->O + 63) / 64 * 64) % 128 == 0 &&
            (long long)g->C * g->H * g->W * 9 * g->B * 4 < (1ll << 31);
 }
 bool want_pix_major(const KanGeom* g, const KanBasis* b, int which) {
@@ -2852,7 +2852,7 @@ BdCfg bd_cfg(const KanGeom* g, const KanPlan& pl) {
 // 128-row tiles inside one tap, 16-image steps, 128-output tiles.
 bool pmdma_bwd_weight(const KanGeom* g, const KanBasis* b) {
     const int f = fast_variant(b);
-    if (tuning_off("KAN_PMDMA") || !(f == 1 || f == 2)) return false;
+    if (tuning_off("KAN_PMDMA") || !(f == 1 || f == 2 || f == 9 || f == 10)) return false;      // B-spline, ReLU-KAN, GRAM-KAN default specs
     if (!want_pix_major(g, b, PM_BWD_WEIGHT)) return false;
     const int P = b->n_basis + (b->act != KAN_ACT_NONE);
     return (g->C * P) % 128 == 0 && g->B % 16 == 0 && round_up(g->O, 64) % 128 == 0 &&
@@ -3516,9 +3516,16 @@ int kan_position_major_expanded(const float* x, float* e_pm, const KanGeom* g, c
     DevBasis db = dev_basis(b);
     dim3 grid(ceil_div(CHW, 32), ceil_div(g->B, 32));
     float* dump = e_pm + (pl.e_pm_elems - 256);
-    // (channel index handed to the basis functor = e / HW: only families with per-channel tables read it, none of which is offered here)
-    if (fast_variant(b) == 1) hipLaunchKernelGGL((k_expand_pm<KAN_BASIS_BSPLINE, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, e_pm, db, g->B, CHW, g->H * g->W, g->x_bstride, dump);
-    else hipLaunchKernelGGL((k_expand_pm<KAN_BASIS_BSPLINE, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, e_pm, db, g->B, CHW, g->H * g->W, g->x_bstride, dump);
+    if ((b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) && !b->chan_table) return fail("ReLU / Gram bases need their device parameter table (chan_table)");
+#define KAN_EXP(KIND, F) hipLaunchKernelGGL((k_expand_pm<KIND, F>), grid, dim3(256), 0, (hipStream_t)stream, x, e_pm, db, g->B, CHW, g->H * g->W, g->C, g->x_bstride, dump)
+    switch (fast_variant(b)) {
+        case 1: KAN_EXP(KAN_BASIS_BSPLINE, 1); break;
+        case 2: KAN_EXP(KAN_BASIS_BSPLINE, 2); break;
+        case 9: KAN_EXP(KAN_BASIS_RELU, 9); break;           // (basis->order selects value / phase-derivative planes)
+        case 10: KAN_EXP(KAN_BASIS_GRAM, 10); break;
+        default: return fail("internal: no expansion kernel for this basis");
+    }
+#undef KAN_EXP
     return launch_ok("position_major_expanded");
 }
 

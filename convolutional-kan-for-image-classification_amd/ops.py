@@ -293,7 +293,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     st = _stream(x)
     z = torch.empty((plan.fwd_splits, B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
     wp, wd = _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, phases, x.device, st)
-    if plan.fwd_expanded and xn is None and phases is None:
+    if plan.fwd_expanded and xn is None:
         # small padded planes: the expanded position-major operand (kept for the weight gradient), DMA + MFMA forward
         e_pm = _expand_pm(x, geom, basis, plan, st)
         _launch("k_conv_fwd_pmdma/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
@@ -368,7 +368,7 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         dwp = torch.empty(plan.bwd_weight_splits * plan.bwd_weight_slab_elems, device=x.device, dtype=torch.float32)
         if plan.bwd_weight_expanded and xn is None and dz_pm is not None:
             # small padded planes: expanded position-major operand, DMA + MFMA weight gradient (kanconv.h)
-            e_pm = x_pm if (plan.fwd_expanded and not plan.x_pm_wanted and x_pm is not None and phases is None) else _expand_pm(x, geom, basis, plan, st)   # the forward's copy, if it kept one
+            e_pm = x_pm if (plan.fwd_expanded and not plan.x_pm_wanted and x_pm is not None and mode == 0) else _expand_pm(x, geom, basis, plan, st)   # the forward's copy, if it kept one (value planes only)
             _launch("k_conv_bwd_weight_pmdma/o" + _tile_tag(plan), _conv_flops(geom, plan), x,
                     lambda: lib.kan_conv_bwd_weight_expanded(_ptr(dz_pm), _ptr(e_pm), _ptr(dwp), C.byref(geom), C.byref(basis), st),
                     _executed_flops(geom, plan, "bwd_weight"), _layer_tag(geom))

@@ -256,3 +256,24 @@ def test_gramkan_halo_kernels_vs_oracle(H, G, B, gpu_lib):
         layer.beta_weights.normal_(0.0, 0.2)
     cfg = _cfg("gram", C, O, k=3, s=1, p=1, d=1, groups=G, degree=3, extra={}, act="silu")
     _check(layer, cfg, torch.randn(B, C, H, H) * 1.5, dict(fam="GRAMKAN", C=C, O=O, G=G, H=H, W=H, B=B, affine=False))
+
+
+@pytest.mark.parametrize("fam,H,B", [("ReLUKAN", 4, 16), ("ReLUKAN", 2, 128), ("GRAMKAN", 4, 32), ("GRAMKAN", 2, 128)])
+def test_parametric_families_on_expanded_position_major_kernels(fam, H, B, gpu_lib):
+    """ReLU-KAN / GRAM-KAN defaults on small padded planes: weight gradient (and its phase / coefficient-derivative passes) on the
+    expanded position-major operand (k_expand_pm with basis->order = mode), ReLU-KAN's 2x2 forward on it too."""
+    from convkan_amd import ops
+    torch.manual_seed(300 + H + B)
+    C = O = 128
+    kw = dict(base_activation=torch.nn.SiLU) if fam == "ReLUKAN" else {}
+    layer = K.CONV_KAN_FACTORY[fam](C, O, 3, **kw)
+    geom, basis, plan = ops._plan_cached(layer.conv_spec(), B, C, H, H, O, C, O)
+    assert plan.bwd_weight_expanded == 1
+    assert plan.fwd_expanded == (1 if (fam == "ReLUKAN" and H == 2 and B % 128 == 0) else 0)
+    with torch.no_grad():
+        if fam == "ReLUKAN":
+            layer.phase_low.add_(0.06 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.06 * torch.randn_like(layer.phase_high))
+        else:
+            layer.beta_weights.normal_(0.0, 0.2)
+    cfg = _cfg("relu" if fam == "ReLUKAN" else "gram", C, O, k=3, s=1, p=1, d=1, groups=1, degree=3, extra={}, act="silu")
+    _check(layer, cfg, torch.randn(B, C, H, H) * 1.5, dict(fam=fam, C=C, O=O, G=1, H=H, W=H, B=B, affine=False))

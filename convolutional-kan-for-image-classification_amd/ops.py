@@ -645,9 +645,37 @@ class _InstanceNorm(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------- public API
+# The kernels address activations with 32-bit byte offsets (buffer loads), so one launch takes tensors below 2 GiB.  Every op
+# on this path is independent per image (conv, per-(image, channel) InstanceNorm, PReLU, pooling), so a larger batch is cut
+# into the fewest equal-ish runs of whole images that fit and the results are concatenated; autograd sums the weight gradients.
+MAX_TENSOR_BYTES = (1 << 31) - 1
+
+
+def _image_runs(spec: ConvSpec, x: torch.Tensor, out_channels: int) -> Optional[int]:
+    """Images per launch if the batch has to be cut (None: it fits)."""
+    B, C, H, W = x.shape
+    Ho, Wo = spec.out_hw(H, W)
+    per_image = 4 * max(C * H * W, out_channels * Ho * Wo)
+    if B * per_image <= MAX_TENSOR_BYTES:
+        return None
+    if per_image > MAX_TENSOR_BYTES:
+        raise L.KanConvError(f"one image's activations ({per_image} bytes) exceed the {MAX_TENSOR_BYTES}-byte launch limit")
+    runs = -(-B * per_image // MAX_TENSOR_BYTES)
+    return -(-B // runs)
+
+
+def _by_image_runs(fn, n: int, x: torch.Tensor, xn: Optional[torch.Tensor] = None) -> torch.Tensor:
+    xs = x.split(n)
+    xns = xn.split(n) if xn is not None else [None] * len(xs)
+    return torch.cat([fn(a.contiguous(), b.contiguous() if b is not None else None) for a, b in zip(xs, xns)])
+
+
 def kan_conv(spec: ConvSpec, x: torch.Tensor, xn: Optional[torch.Tensor], w_base: Sequence[torch.Tensor],
              w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
+    n = _image_runs(spec, x, sum(w.shape[0] for w in w_basis))
+    if n is not None:
+        return _by_image_runs(lambda a, b: _KanConv.apply(spec, a, b, *ws), n, x, xn)
     return _KanConv.apply(spec, x, xn, *ws)
 
 
@@ -656,6 +684,9 @@ def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_bas
     """Conv stage of a basis with trainable parameters held in device memory, differentiable in them: ReLU-KAN
     (`phases` = [channels per group, 2, n_basis]: low, high) or Gram (`phases` = [n_basis] recurrence coefficients c_k)."""
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
+    n = _image_runs(spec, x, sum(w.shape[0] for w in w_basis))
+    if n is not None:
+        return _by_image_runs(lambda a, _: _KanConvPhased.apply(spec, a, phases, *ws), n, x)
     return _KanConvPhased.apply(spec, x, phases, *ws)
 
 
@@ -666,6 +697,9 @@ def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Te
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     aff = gammas is not None
     extra = (list(gammas) + list(betas) if aff else []) + (list(prelus) if prelus is not None else [])
+    n = _image_runs(spec, x, sum(w.shape[0] for w in w_basis))
+    if n is not None:
+        return _by_image_runs(lambda a, _: _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), a, *ws, *extra), n, x)
     return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), x, *ws, *extra)
 
 

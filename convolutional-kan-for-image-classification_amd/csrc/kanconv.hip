@@ -649,7 +649,9 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
         pbase = g.pix_major ? (hi0 * g.W + wi0) * g.B + b : b * (int)g.xbs + hi0 * g.W + wi0;
     }
     const int estride = g.pix_major ? g.B : 1;               // element stride of the (c,hi,wi) index
-    const bool same_in = (KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);     // FastKAN / LegendreKAN evaluate their basis on a second tensor
+    // FastKAN / LegendreKAN evaluate their basis on a second tensor, and so does any layer whose base activation the host applied
+    // (x = act(input), xn = input, act = identity); the compile-time specs of the other kinds are single-input by construction
+    const bool same_in = (FAST != 0 && KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);
     const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes);
     const int wv = wave;
     const unsigned wlane = (unsigned)((lane / (TO / 4)) * Opad + (lane % (TO / 4)) * 4) * 4u;   // this lane inside a 1-KiB weight block
@@ -1392,7 +1394,7 @@ __global__ __launch_bounds__(WR * WC * 64, (WR * WC > 4 ? 2 : 4)) void k_conv_bw
         }
         sItem[i] = v;
     }
-    const bool same_in = (KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);
+    const bool same_in = (FAST != 0 && KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);
     __syncthreads();
 
     float xa[UPF], xb[UPF], zr[ZL]; unsigned inb_mask = 0;
@@ -3324,6 +3326,8 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         else KAN_FWD(KIND, 1, 2, 16);                                          \
     } while (0)
     const int fast = fast_variant(b);
+    if (x != xn && fast != 0 && b->kind != KAN_BASIS_RBF && b->kind != KAN_BASIS_POLY)
+        return fail("this basis / activation pair runs on single-input kernels: pass xn == x");
 #define KAN_FWD_FAST(KIND, F, KCV) do { if (c.TO == 128) KAN_FWD2(KIND, F, 2, 2, KCV); else KAN_FWD2(KIND, F, 1, 2, KCV); } while (0)
     if (c.TO == 256 && fast == 1) KAN_FWD2(KAN_BASIS_BSPLINE, 1, 4, 2, 18);
     else if (c.TO == 256 && fast == 2) KAN_FWD2(KAN_BASIS_BSPLINE, 2, 4, 2, 18);
@@ -3479,6 +3483,8 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     hipLaunchKernelGGL((k_conv_bwd_weight<KIND, FAST, WR, WC>), grid, dim3(WR * WC * 64), 0, st, dz, x, xn, dwp, dg, db, pl.K, pl.Opad, c.chunks, cps, pl.bwd_weight_slab_elems, (unsigned)((long long)g->B * g->x_bstride * 4), (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o)
 #define KAN_BW_KIND(KIND) do { if (c.TO == 128) KAN_BW(KIND, 2, 2); else KAN_BW(KIND, 4, 1); } while (0)
     const int fast = fast_variant(b);
+    if (x != xn && fast != 0 && b->kind != KAN_BASIS_RBF && b->kind != KAN_BASIS_POLY)
+        return fail("this basis / activation pair runs on single-input kernels: pass xn == x");
 #define KAN_BW_FAST(KIND, F) do { if (c.TO == 128) KAN_BW2(KIND, F, 2, 2); else KAN_BW2(KIND, F, 4, 1); } while (0)
     if (c.TO == 256 && fast == 1) KAN_BW2(KAN_BASIS_BSPLINE, 1, 2, 4);
     else if (c.TO == 256 && fast == 2) KAN_BW2(KAN_BASIS_BSPLINE, 2, 2, 4);

@@ -43,15 +43,23 @@ def _pair(v):
 _ACT_CODES = {nn.Identity: L.ACT_IDENTITY, nn.SiLU: L.ACT_SILU, nn.ReLU: L.ACT_RELU, nn.Tanh: L.ACT_TANH, nn.Sigmoid: L.ACT_SIGMOID}
 
 
-def _act_code(module: nn.Module) -> int:
-    """Map the instantiated ``base_activation`` module to a kernel activation id."""
+def _act_code(module: nn.Module, host_ok: bool = False) -> int:
+    """Map the instantiated ``base_activation`` module to a kernel activation id.  A module without a device functor is
+    applied by the host (``_HipLayer._base_input``) where the layer supports that (`host_ok`): the kernels then see the
+    activated tensor as their base-branch input with the identity functor, and the raw input as the basis tensor."""
     if type(module) is nn.GELU:
         return L.ACT_GELU_TANH if getattr(module, "approximate", "none") == "tanh" else L.ACT_GELU
     code = _ACT_CODES.get(type(module))
     if code is None:
+        if host_ok:
+            return L.ACT_IDENTITY
         raise NotImplementedError(
             f"base_activation {type(module).__name__} has no HIP functor yet (supported: Identity/None, GELU, SiLU, ReLU, Tanh, Sigmoid)")
     return code
+
+
+def _host_applied(module: nn.Module) -> bool:
+    return type(module) is not nn.GELU and type(module) not in _ACT_CODES
 
 
 def _dropout2d(p: float, ndim: int = 2):
@@ -185,6 +193,28 @@ class _HipLayer(nn.Module):
             return [m.weight for m in mods], [m.bias for m in mods]
         return None, None
 
+    def _base_input(self, x):
+        """(base-branch tensor, basis tensor or None): `(act(x), x)` when the host applies the activation (no device functor
+        for this module; the kernels run their two-input form with the identity functor), else `(x, None)`."""
+        if _host_applied(self.base_activation):
+            return self.base_activation(x), x
+        return x, None
+
+    def _norm_prelu(self, z):
+        """Un-fused tail for the (lifted) [B, O, H, W] pre-norm tensor: the InstanceNorm kernel (or the caller's own norm
+        modules on the layer's own rank), then PReLU.  Returns the tensor in the layer's rank."""
+        og, mods = self.output_dim_group, self.layer_norm
+        if _fusable_instnorm(mods):
+            gam = torch.cat([m.weight for m in mods]) if mods[0].affine else None
+            bet = torch.cat([m.bias for m in mods]) if mods[0].affine else None
+            n = self._lower(ops.instance_norm(z.contiguous(), gam, bet, eps=mods[0].eps))
+            parts = [n[:, g * og:(g + 1) * og] for g in range(self.groups)]
+        else:
+            z = self._lower(z)
+            parts = [mods[g](z[:, g * og:(g + 1) * og]) for g in range(self.groups)]
+        parts = [self.prelus[g](t) for g, t in enumerate(parts)]
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+
 
 # =========================================================================================== B-spline
 class KANConvNDLayer(_HipLayer):
@@ -221,7 +251,7 @@ class KANConvNDLayer(_HipLayer):
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.spline_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
-        self._act_code = _act_code(self.base_activation)
+        self._act_code = _act_code(self.base_activation, host_ok=True)
 
     def _basis_kw(self):
         return dict(kind=L.BASIS_BSPLINE, n_basis=self.grid_size + self.spline_order, order=self.spline_order,
@@ -231,7 +261,8 @@ class KANConvNDLayer(_HipLayer):
         return self._spec(**self._basis_kw())
 
     def _forward3d(self, x):
-        z = conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, x, None,
+        xa, xb = self._base_input(x)
+        z = conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, xa, xb,
                          [m.weight for m in self.base_conv], [m.weight for m in self.spline_conv])
         y = _norm3d(self.layer_norm, self.prelus, z, self.output_dim_group)
         return self.dropout(y) if self.dropout is not None else y
@@ -247,7 +278,8 @@ class KANConvNDLayer(_HipLayer):
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.spline_conv)
         prelus = [m.weight for m in self.prelus]
-        if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
+        xa, xb = self._base_input(x)
+        if xb is None and _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
             if pool and self.ndim == 2 and self.dropout is None:
                 ho, wo = spec.out_hw(x.shape[2], x.shape[3])
@@ -255,10 +287,8 @@ class KANConvNDLayer(_HipLayer):
                     return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
-            # other norm classes (e.g. BatchNorm2d): HIP conv stage, then the caller's own norm module
-            z = self._lower(ops.kan_conv(spec, x, None, wb, ws))
-            og = self.output_dim_group
-            y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
+            # other norm classes (e.g. BatchNorm2d) or a host-applied activation: HIP conv stage, then the un-fused tail
+            y = self._norm_prelu(ops.kan_conv(spec, xa, xb, wb, ws))
         if self.dropout is not None:
             y = self.dropout(y)
         return F.max_pool2d(y, 2, 2) if pool else y
@@ -328,7 +358,7 @@ class FastKANConvNDLayer(_HipLayer):
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.spline_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
-        self._act_code = _act_code(self.base_activation)
+        self._act_code = _act_code(self.base_activation, host_ok=True)
         self._centres = tuple(float(v) for v in self.rbf.grid.detach().tolist())
 
     def _basis_kw(self):
@@ -348,7 +378,7 @@ class FastKANConvNDLayer(_HipLayer):
             xn = ops.instance_norm(xs.reshape(B, C, D * H, W), gam, bet, eps=self.layer_norm[0].eps).view(B, C, D, H, W)
         else:
             xn = torch.cat([self.layer_norm[g](xs[:, g * cg:(g + 1) * cg]) for g in range(self.groups)], dim=1)
-        return conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, x, xn,
+        return conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, self._base_input(x)[0], xn,
                             [m.weight for m in self.base_conv], [m.weight for m in self.spline_conv])
 
     def forward(self, x):
@@ -367,7 +397,7 @@ class FastKANConvNDLayer(_HipLayer):
             xn = ops.instance_norm(xn.contiguous(), gam, bet, eps=self.layer_norm[0].eps)
         else:
             xn = self._lift(torch.cat([self.layer_norm[g](xs[:, g * cg:(g + 1) * cg]) for g in range(self.groups)], dim=1))
-        return self._lower(ops.kan_conv(self.conv_spec(), self._lift(x), xn, self._w(self.base_conv), self._w(self.spline_conv)))
+        return self._lower(ops.kan_conv(self.conv_spec(), self._lift(self._base_input(x)[0]), xn, self._w(self.base_conv), self._w(self.spline_conv)))
 
 
 class FastKANConv1DLayer(FastKANConvNDLayer):

@@ -18,7 +18,7 @@ import torch.nn.functional as F
 
 from .. import _lib as L
 from .. import ops
-from .conv_layers import _act_code
+from .conv_layers import _act_code, _host_applied
 
 
 class KANLayer(nn.Module):
@@ -38,7 +38,7 @@ class KANLayer(nn.Module):
                                    grid_size + 2 * spline_order + 1, dtype=torch.float32).expand(input_features, -1).contiguous()
         nn.init.kaiming_uniform_(self.base_weight, nonlinearity='linear')
         nn.init.kaiming_uniform_(self.spline_weight, nonlinearity='linear')
-        self._act_code = _act_code(self.base_activation)
+        self._act_code = _act_code(self.base_activation, host_ok=True)
 
     def conv_spec(self) -> ops.ConvSpec:
         return ops.ConvSpec(kind=L.BASIS_BSPLINE, n_basis=self.grid_size + self.spline_order, order=self.spline_order, act=self._act_code,
@@ -49,7 +49,9 @@ class KANLayer(nn.Module):
         if x.dim() != 2:
             raise ValueError("KANLayer expects [batch, features] (kan_layers.py:100-104 views the bases as [batch, in*n])")
         B, I, O = x.shape[0], self.input_features, self.output_features
-        z = ops.kan_conv(self.conv_spec(), x.reshape(B, I, 1, 1), None, [self.base_weight.view(O, I, 1, 1)],
+        host = _host_applied(self.base_activation)            # no device functor: act(x) feeds the base branch, x the splines
+        xa = self.base_activation(x) if host else x
+        z = ops.kan_conv(self.conv_spec(), xa.reshape(B, I, 1, 1), x.reshape(B, I, 1, 1) if host else None, [self.base_weight.view(O, I, 1, 1)],
                          [self.spline_weight.view(O, I * (self.grid_size + self.spline_order), 1, 1)])
         return self.prelu(self.layer_norm(z.view(B, O)))
 

@@ -77,7 +77,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.poly_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
-        self._act_code = _act_code(self.base_activation)
+        self._act_code = _act_code(self.base_activation, host_ok=True)
         if self._n_planes() > 11:
             raise NotImplementedError("the HIP recurrence basis holds at most 11 planes per channel (degree <= 10)")
 
@@ -97,7 +97,8 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.poly_conv)
         prelus = [m.weight for m in self.prelus]
-        if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
+        xa, xb = self._base_input(x)                              # (act(x), x) when the host applies the activation
+        if xb is None and _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
             if pool and self.dropout is None and self.ndim == 2:
                 ho, wo = spec.out_hw(x.shape[2], x.shape[3])
@@ -105,9 +106,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
                     return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
-            z = self._lower(ops.kan_conv(spec, x, None, wb, ws))
-            og = self.output_dim_group
-            y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
+            y = self._norm_prelu(ops.kan_conv(spec, xa, xb, wb, ws))
         if self.dropout is not None:
             y = self.dropout(y)
         return torch.nn.functional.max_pool2d(y, 2, 2) if pool else y
@@ -384,7 +383,7 @@ class FourierKANConvNDLayer(_HipLayer):
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
         for conv in self.fourier_conv:
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
-        self._act_code = _act_code(self.base_activation)
+        self._act_code = _act_code(self.base_activation, host_ok=True)
 
     def conv_spec(self) -> ops.ConvSpec:
         return self._spec(kind=L.BASIS_FOURIER, n_basis=2 * self.grid_size, order=0, act=self._act_code, p0=0.0, p1=0.0, table=())
@@ -394,13 +393,12 @@ class FourierKANConvNDLayer(_HipLayer):
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.fourier_conv)
         prelus = [m.weight for m in self.prelus]
-        if _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
+        xa, xb = self._base_input(x)                              # (act(x), x) when the host applies the activation
+        if xb is None and _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
-            z = self._lower(ops.kan_conv(spec, x, None, wb, ws))
-            og = self.output_dim_group
-            y = torch.cat([self.prelus[g](self.layer_norm[g](z[:, g * og:(g + 1) * og])) for g in range(self.groups)], dim=1)
+            y = self._norm_prelu(ops.kan_conv(spec, xa, xb, wb, ws))
         if self.dropout is not None:
             y = self.dropout(y)
         return y

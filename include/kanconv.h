@@ -157,7 +157,9 @@ int kan_pack_weights_cached(const float* w_base, const float* w_basis, float* wp
  *                                     Cox-de Boor, moveaxis/flatten, two convs, add)
  *   fast_kan_layers.py:103, 106-109  (RBF; xn = normalised input, x = raw input)
  *   cheby_kan_layers.py:93-97        (Chebyshev; no base branch)
- * `xn` is the tensor the basis is evaluated on (== x except for FastKAN).
+ * `xn` is the tensor the basis is evaluated on (== x except for FastKAN / LegendreKAN, and for a host-applied base
+ * activation: x = act(input), xn = input, act = KAN_ACT_IDENTITY).  The compile-time specs of the single-input kinds
+ * (default B-spline with SiLU/GELU, ChebyKAN, ReLU-KAN, GRAM) reject xn != x.
  * z holds plan.fwd_splits slabs of plan.fwd_slab_elems elements; their sum is the result
  * (kan_instnorm_prelu_fwd / kan_slab_reduce consume slabs directly). */
 int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z,

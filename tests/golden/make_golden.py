@@ -37,9 +37,12 @@ from layers import KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv1DLayer  # no
 from layers import KANLayer as RefKANLayer  # noqa: E402  (reference, layers/kan_layers.py:8-114)
 from oracle import kan_oracle as O  # noqa: E402
 
-ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid,
+        # modules the HIP library has no functor for: the host applies them (layers/conv_layers.py `_base_input`)
+        "softplus": nn.Softplus, "mish": nn.Mish, "elu": nn.ELU, "lrelu": nn.LeakyReLU, "hswish": nn.Hardswish}
 NORMS = {"in": nn.InstanceNorm2d, "bn": nn.BatchNorm2d}
-ACT_FN = {"gelu": F.gelu, "silu": F.silu, "none": None, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+ACT_FN = {"gelu": F.gelu, "silu": F.silu, "none": None, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+          "softplus": F.softplus, "mish": F.mish, "elu": F.elu, "lrelu": F.leaky_relu, "hswish": F.hardswish}
 
 
 def det_fill(t: torch.Tensor, salt: int, scale: float):
@@ -194,6 +197,20 @@ GRAM_CASES = [
     C("gram", "deg1_k5", 2, 3, 5, 9, 9, k=5, p=2, degree=1),
     C("gram", "wide_deg6", 3, 20, 40, 6, 6, degree=6, xs=2.0),
     C("gram", "batchnorm_d2", 3, 4, 8, 8, 8, degree=2, d=2, p=2, norm="bn"),
+]
+
+
+# ---- base activations without a device functor (any nn.Module is legal in the reference: kan_layers.py:132)
+HOSTACT_CASES = [
+    C("bspline", "act_softplus", 2, 3, 4, 8, 8, act="softplus"),
+    C("bspline", "act_mish_s2g2_affine", 3, 4, 6, 9, 7, s=2, groups=2, act="mish", norm_kwargs={"affine": True}),
+    C("bspline", "act_elu_bn", 3, 4, 8, 8, 8, act="elu", norm="bn", xs=2.0),
+    C("bspline", "1d_act_lrelu", 2, 3, 4, 1, 20, ndim=1, act="lrelu"),
+    C("bspline", "3d_act_hswish", 2, 3, 4, 6, 6, ndim=3, D=5, act="hswish"),
+    C("rbf", "act_mish", 2, 3, 4, 8, 8, act="mish"),
+    C("rbf", "3d_act_softplus_g2", 2, 4, 6, 6, 6, ndim=3, D=4, groups=2, act="softplus"),
+    C("hermite", "act_softplus", 2, 3, 4, 8, 8, degree=3, act="softplus"),
+    C("fourier", "act_elu_g2", 2, 4, 6, 7, 5, groups=2, degree=3, act="elu"),
 ]
 
 
@@ -443,6 +460,7 @@ MLP_CASES = [
     dict(name="head512", B=64, I=512, O=10, G=5, S=3, act="silu", rng=[-1, 1], xs=1.0),      # KAN head of kan_vgg.py:134-138
     dict(name="wide", B=33, I=40, O=130, G=8, S=2, act="none", rng=[-2, 2], xs=2.5),
     dict(name="order1", B=16, I=24, O=40, G=3, S=1, act="tanh", rng=[-1, 1], xs=0.7),
+    dict(name="act_softplus", B=9, I=12, O=7, G=5, S=3, act="softplus", rng=[-1, 1], xs=1.0),     # host-applied activation
 ]
 
 
@@ -529,6 +547,12 @@ def cases_3d():
     for i, c in enumerate(CASES_3D):
         worst, sz = run_case(7200 + i, c)
         print(f"{c['kind']:10s} {c['name']:14s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
+def hostact_cases():
+    for i, c in enumerate(HOSTACT_CASES):
+        worst, sz = run_case(7300 + i, c)
+        print(f"{c['kind']:10s} {c['name']:22s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 
 
 def mlp_cases():
@@ -686,6 +710,8 @@ def main():
         return gram_cases()
     if "--3d-only" in sys.argv:
         return cases_3d()
+    if "--hostact-only" in sys.argv:                # base activations the host applies
+        return hostact_cases()
     if "--model-only" in sys.argv:                  # the two model fixtures + their tolerance calibration
         return model_cases()
     total = 0
@@ -700,6 +726,7 @@ def main():
     relu_cases()
     gram_cases()
     cases_3d()
+    hostact_cases()
     model_cases()
     print(f"total layer fixtures: {total / 1e6:.2f} MB")
 

@@ -3,9 +3,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+ACTS = {"gelu": nn.GELU, "silu": nn.SiLU, "none": None, "relu": nn.ReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid,
+        "softplus": nn.Softplus, "mish": nn.Mish, "elu": nn.ELU, "lrelu": nn.LeakyReLU, "hswish": nn.Hardswish}    # applied by the host
 NORMS = {"in": nn.InstanceNorm2d, "bn": nn.BatchNorm2d}
-ACT_FN = {"gelu": F.gelu, "silu": F.silu, "none": None, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid}
+ACT_FN = {"gelu": F.gelu, "silu": F.silu, "none": None, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+          "softplus": F.softplus, "mish": F.mish, "elu": F.elu, "lrelu": F.leaky_relu, "hswish": F.hardswish}
 DEFAULT_ACT = {"bspline": "gelu", "rbf": "silu"}
 
 # fp32 tolerances, max-normalised per tensor (the reference's own fp32-vs-fp64 noise is

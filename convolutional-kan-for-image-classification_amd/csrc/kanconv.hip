@@ -54,6 +54,32 @@ __device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)
         }                                                                                                                          \
     } while (0)
 
+// The same step with the two pixel blocks of the wave individually switchable in each half of the k-pairs (wave-uniform flags:
+// scalar branches around two MFMAs): l0a / l0b = pixel block 0 alive in the first / second NK/2 k-pairs, l1a / l1b likewise block 1
+#define KAN_MFMA_STEP_LIVE(NK, addrA, LDA, addrB, LDB, l0a, l0b, l1a, l1b)                                                          \
+    do {                                                                                                                           \
+        float fa_[2][2], fb_[2][2];                                                                                                \
+        LDS_READ4(fa_[0][0], fa_[0][1], fb_[0][0], fb_[0][1], addrA, addrB, 0, 32 * 4, 0, 32 * 4);                                 \
+        _Pragma("unroll") for (int kk = 0; kk < (NK); ++kk) {                                                                       \
+            const int c_ = kk & 1, n_ = c_ ^ 1;                                                                                    \
+            if (kk + 1 < (NK)) {                                                                                                   \
+                LDS_READ4(fa_[n_][0], fa_[n_][1], fb_[n_][0], fb_[n_][1], addrA, addrB, (2 * (kk + 1)) * (LDA) * 4,                \
+                          (2 * (kk + 1)) * (LDA) * 4 + 128, (2 * (kk + 1)) * (LDB) * 4, (2 * (kk + 1)) * (LDB) * 4 + 128);         \
+                LDS_WAIT4(fa_[c_][0], fa_[c_][1], fb_[c_][0], fb_[c_][1], 4);                                                      \
+            } else {                                                                                                               \
+                LDS_WAIT4(fa_[c_][0], fa_[c_][1], fb_[c_][0], fb_[c_][1], 0);                                                      \
+            }                                                                                                                      \
+            if (kk < (NK) / 2 ? (l0a) : (l0b)) {                                                                                   \
+                acc[0][0] = MFMA32(fa_[c_][0], fb_[c_][0], acc[0][0]);                                                             \
+                acc[1][0] = MFMA32(fa_[c_][1], fb_[c_][0], acc[1][0]);                                                             \
+            }                                                                                                                      \
+            if (kk < (NK) / 2 ? (l1a) : (l1b)) {                                                                                   \
+                acc[0][1] = MFMA32(fa_[c_][0], fb_[c_][1], acc[0][1]);                                                             \
+                acc[1][1] = MFMA32(fa_[c_][1], fb_[c_][1], acc[1][1]);                                                             \
+            }                                                                                                                      \
+        }                                                                                                                          \
+    } while (0)
+
 namespace {
 
 
@@ -795,8 +821,13 @@ __global__ __launch_bounds__(WO * WP * 64, (WO * WP > 4 ? 2 : 4)) void k_conv_fw
     asm volatile("ds_read_b32 %0, %4 offset:%7\n\tds_read_b32 %1, %4 offset:%8\n\tds_read_b32 %2, %5 offset:%9\n\tds_read_b32 %3, %6 offset:%9" \
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(addrA), "v"(addrB0), "v"(addrB1), "n"(oA0), "n"(oA1), "n"(oB) : "memory")
 
+#define LDS_READ3H(r0, r1, r2, addrA, addrB, oA0, oA1, oB)                                                               \
+    asm volatile("ds_read_b32 %0, %3 offset:%5\n\tds_read_b32 %1, %3 offset:%6\n\tds_read_b32 %2, %4 offset:%7"         \
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(addrA), "v"(addrB), "n"(oA0), "n"(oA1), "n"(oB) : "memory")
+#define LDS_WAIT3(r0, r1, r2, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(r0), "+v"(r1), "+v"(r2) :: "memory")
+
 template <int FAST, int WO, int W, int R, int NIMG>
-__global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo(
+__global__ __launch_bounds__(WO * 2 * 64, ((WO > 2 && !(R * W == 16 && NIMG * W == 32)) ? 2 : 4)) void k_conv_fwd_halo(
     const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ z, DevGeom g, DevBasis bs, int Opad,
     int n_pairs, int pairs_per_split, long long slab_elems, unsigned x_bytes, int tiles_o) {
     constexpr int TO = WO * 64, TP = 128, NT = WO * 2 * 64, NW = WO * 2, P = fast_planes(FAST), KC = 2 * P, T = 9;
@@ -804,6 +835,13 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
     constexpr int HW_ = W + 2, HIMG = (R + 2) * HW_, HALO = NIMG * HIMG;          // cells per plane
     constexpr int RPI = 256 / TO, NQ = (KC + RPI - 1) / RPI;
     static_assert(NIMG * R * W == TP && HALO % 2 == 0, "tile shape");
+    // Whole planes of 4 rows in a tile (4x4 planes): the tile's pixels are ordered row-major ACROSS the images, n = (row, image, column),
+    // so a 32-pixel MFMA block is one output row of all 8 images -- and for the taps whose source row leaves the plane (tap row 0 under
+    // output row 0, tap row 2 under the last row) the whole block multiplies the zero border: its MFMAs are skipped (exact:
+    // the skipped products are all zero).  A wave owns two rows, so it skips half of its work in 3 of the 9 steps; with 8 waves the
+    // pixel half is chosen by wave >> 2, which puts one wave of each half on every SIMD -- the matrix pipe of a SIMD then sees 6 instead
+    // of 8 MFMAs per k-pair in 6 of 9 steps (with wave & 1 the skipping waves share two SIMDs and the others wait at the step barrier: -2 % only).
+    constexpr bool ROWBLK = (R * W == 16 && NIMG * W == 32 && WO == 4);
     __shared__ __attribute__((aligned(16))) float sW[2 * KC * TO];
     __shared__ float sH[2 * P * HALO];
     __shared__ float sTab[KAN_MAX_TABLE];
@@ -811,7 +849,7 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w_o = wave >> 1, w_p = wave & 1;
+    const int w_o = ROWBLK ? (wave & 3) : (wave >> 1), w_p = ROWBLK ? (wave >> 2) : (wave & 1);
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, Mtot = g.B * HoWo;
     const BlockId blk = xcd_block_order(true);
     const int grp = blk.y / tiles_o;
@@ -848,7 +886,8 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int n = w_p * 64 + q * 32 + (lane & 31);
-        const int img = n / (R * W), rem = n - img * (R * W), row = rem / W, col = rem - row * W;
+        int img = n / (R * W), rem = n - img * (R * W), row = rem / W, col = rem - row * W;
+        if (ROWBLK) { row = n / (NIMG * W); rem = n - row * (NIMG * W); img = rem / W; col = rem - img * W; }
         vb[q] = lds_addr(sH + kh2 * (P * HALO) + img * HIMG + (row + 1) * HW_ + (col + 1));
     }
     const int ao = w_o * 64 + (lane & 31);
@@ -904,6 +943,9 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
             const unsigned sh = (unsigned)(((r - 1) * HW_ + (t - 1)) * 4);
             const unsigned aw = lds_addr(sW + buf * (KC * TO) + kh2 * TO + ao), ab0 = vb[0] + sh, ab1 = vb[1] + sh;
             float fa[2][2], fb[2][2];
+            // (ROWBLK) this wave's rows are 2 * w_p and 2 * w_p + 1: which of its two pixel blocks this tap leaves alive
+            const int dead = !ROWBLK ? -1 : (r == 0 && w_p == 0) ? 0 : (r == 2 && w_p == 1) ? 1 : -1;
+            const bool live0 = dead != 0, live1 = dead != 1;                  // wave-uniform: scalar branches around two MFMAs each
             LDS_READ4H(fa[0][0], fa[0][1], fb[0][0], fb[0][1], aw, ab0, ab1, 0, 32 * 4, 0);
 #pragma unroll
             for (int kk = 0; kk < P; ++kk) {
@@ -915,10 +957,14 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
                 } else {
                     LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 0);
                 }
-                acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);
-                acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);
-                acc[1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[1][0]);
-                acc[1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[1][1]);
+                if (!ROWBLK || live0) {
+                    acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);
+                    acc[1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[1][0]);
+                }
+                if (!ROWBLK || live1) {
+                    acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);
+                    acc[1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[1][1]);
+                }
             }
             buf ^= 1;
         }
@@ -928,7 +974,11 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
     float* zs = z + (size_t)blk.z * slab_elems;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int px = px_tile0 + w_p * 64 + ni * 32 + (lane & 31);
+        int px = px_tile0 + w_p * 64 + ni * 32 + (lane & 31);
+        if (ROWBLK) {                                        // n = (row, image, column) -> the plane-major pixel index
+            const int l = lane & 31;
+            px = px_tile0 + (l >> 2) * (R * W) + (w_p * 2 + ni) * W + (l & 3);
+        }
         if (px >= Mtot) continue;
         const int b = px / HoWo, hw = px - b * HoWo;
         float* zb = zs + (size_t)b * g.ybs + hw;
@@ -948,7 +998,14 @@ __global__ __launch_bounds__(WO * 2 * 64, (WO > 2 ? 2 : 4)) void k_conv_fwd_halo
 // zero), x 128 input pixels.  Depth steps: (tap, 16 outputs); weights come from the wd layout (straight 16 x 128
 // copy), dz is gathered at the output position each (input pixel, tap) pair feeds.
 // Epilogue, one half at a time (32 KB of LDS): G half-tile -> LDS, then dx = sum_p plane_p'(x) * G_p.
-template <int KIND, int FAST>
+// RB = 1 (4x4 planes, 3x3 / stride 1 / pad 1, tiles of 8 whole images): the tile's pixels are ordered (row, image, column) as in the halo
+// forward, so a 32-pixel MFMA block is one input row of all 8 images; for the taps that reach it only from outside the plane (tap row 2
+// for row 0, tap row 0 for row 3) the gathered dz block is all zero and its MFMAs are skipped (exact).  A wave owns two rows; so that both
+// pixel halves skip the SAME amount between two barriers (a wave that skips alone just waits for the others), the depth order pairs the
+// outer tap rows: a mixed step holds 8 outputs of tap (0, t) in its first four k-pairs and the same 8 outputs of tap (2, t) in the last
+// four -- the waves of rows 0-1 skip a block in the second half, those of rows 2-3 in the first: 24 instead of 32 MFMAs each.  The middle
+// tap row keeps plain 16-output steps.  Step index: [0, 3 n_ob) plain (t, output block), then (t, 8-output group) mixed.
+template <int KIND, int FAST, int RB = 0>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
     float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CH, int n_ct, int n_ob, int Opad16,
@@ -978,7 +1035,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     }
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
-    const int my_px = px_tile0 + pxl;
+    // tile column pxl holds pixel my_px: plane-major, or (RB) column = (row, image, column) -> pixel = image * 16 + row * 4 + column
+    const int my_px = px_tile0 + (RB ? ((pxl >> 2) & 7) * 16 + (pxl >> 5) * 4 + (pxl & 3) : pxl);
     const bool pv = my_px < Min;
     int pb, ph_, pw_;
     {
@@ -1040,6 +1098,48 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         }
     };
 
+    // (RB) the paired depth order: plain steps of the middle tap row, then mixed steps (rows 0-7: tap (0,t), rows 8-15: tap (2,t))
+    int rb_t = -1; unsigned baseA = KAN_OOB, baseB = KAN_OOB; bool pend_mixed = false;
+    auto issue_rb = [&](int ch, int buf) {
+        const int n_plain = 3 * n_ob;
+        const bool mixed = ch >= n_plain;
+        pend_mixed = mixed;
+        int t, o0;                                                                     // scalar
+        if (mixed) { const int m = ch - n_plain; t = m / (2 * n_ob); o0 = (m - t * 2 * n_ob) * 8; }
+        else { t = ch / n_ob; o0 = (ch - t * n_ob) * KD; }
+        const int key = mixed ? 3 + t : t;
+        if (key != rb_t) {                                                             // uniform: once per tap (pair)
+            rb_t = key;
+            const int wn = pw_ + 1 - t;
+            const bool okw = pv && wn >= 0 && wn < 4;
+            const int hA = ph_ + 1 - (mixed ? 0 : 1), hB = ph_ + 1 - 2;                // source rows under tap row 0 (or 1) and 2
+            baseA = (okw && hA >= 0 && hA < 4) ? (dz_img + (unsigned)(hA * 4 + wn)) * 4u : KAN_OOB;
+            baseB = (okw && hB >= 0 && hB < 4) ? (dz_img + (unsigned)(hB * 4 + wn)) * 4u : KAN_OOB;
+        }
+        float* dW = smem + buf * (2 * KD * 128);
+        float* dG = dW + KD * 128 + (wv & 1) * 64;
+        // (the host takes this kernel only when O is a multiple of 16: no ragged output block, scalar row offsets)
+        const unsigned soA = (unsigned)(o0 + ol0) * row_bytes;
+        if (mixed) {
+#pragma unroll
+            for (int n = 0; n < 8; ++n)                    // row ol0 + 2n: output o0 + ((ol0 + 2n) & 7) of tap A (n < 4) or B
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dG + (ol0 + 2 * n) * TP), 4,
+                                                         (int)(n < 4 ? baseA : baseB), (int)(soA + (unsigned)(2 * (n & 3)) * row_bytes), 0, 0);
+        } else {
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dG + (ol0 + 2 * n) * TP), 4,
+                                                         (int)baseA, (int)(soA + (unsigned)(2 * n) * row_bytes), 0, 0);
+        }
+        const int tapA = mixed ? t : 3 + t, tapB = 6 + t;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                      // 16 rows x 512 B = 8 wave-instructions of 1 KiB (2 rows each)
+            const int blk2 = j * 4 + wv;
+            const int row = mixed ? ((blk2 < 4 ? tapA : tapB) * Opad16 + o0 + (blk2 & 3) * 2) : (tapA * Opad16 + o0 + blk2 * 2);      // scalar
+            glds16((const float*)((const char*)(wd + (size_t)row * ncol + ct * 128) + wlane), dW + blk2 * 256);
+        }
+    };
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1076,17 +1176,22 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         return ch1;
     };
     int ch = next_live(ch0);
-    if (ch < ch1) issue(ch, 0);
+    if (ch < ch1) { if (RB) issue_rb(ch, 0); else issue(ch, 0); }
     const int ar = w_r * 64 + (lane & 31), bp = w_p * 64 + (lane & 31), kh2 = lane >> 5;
     for (int cur = 0; ch < ch1; cur ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's async copies of the step have landed ...
         __syncthreads();                                   // ... and so have everyone else's; also orders the two buffers
+        const bool mixed_now = pend_mixed;
         ch = next_live(ch + 1);
-        if (ch < ch1) issue(ch, cur ^ 1);
+        if (ch < ch1) { if (RB) issue_rb(ch, cur ^ 1); else issue(ch, cur ^ 1); }
         const float* cW = smem + cur * (2 * KD * 128);
         const float* cG = cW + KD * 128;
         const unsigned aw = lds_addr(cW + kh2 * 128 + ar), ag = lds_addr(cG + kh2 * TP + bp);
-        if (!idle_rows) KAN_MFMA_STEP(KD / 2, aw, 128, ag, TP);     // (waves whose 64 rows hold no channel leave the matrix pipe to others)
+        if (RB) {
+            // rows 2 w_p and 2 w_p + 1: row 0 has no source under tap row 2 (second half of a mixed step), row 3 none under tap row 0 (first half)
+            const bool l0b = !(mixed_now && w_p == 0), l1a = !(mixed_now && w_p == 1);
+            if (!idle_rows) KAN_MFMA_STEP_LIVE(KD / 2, aw, 128, ag, TP, true, l0b, l1a, true);
+        } else if (!idle_rows) KAN_MFMA_STEP(KD / 2, aw, 128, ag, TP);     // (waves whose 64 rows hold no channel leave the matrix pipe to others)
     }
 
     // ---- epilogue: per 64-row half, G -> LDS, contract the P planes of each channel with plane'(x)
@@ -3403,7 +3508,14 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     // compile-time epilogues: single-input specs need x == xn and one output; the FastKAN specs need both tensors
     const int fv = fast_variant(b);
     const int fast = (fv == 3 || fv == 8) ? ((x != xn && dxn) ? fv : 0) : ((x == xn && !dxn) ? fv : 0);
-    if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);
+    // 4x4 planes in tiles of 8 whole images: row-ordered pixel blocks, dead (row, tap row) blocks skipped (see the kernel)
+    const bool rb = !dg.pix_major && !tuning_off("KAN_BD_ROWBLK") && g->H == 4 && g->W == 4 && g->Ho == 4 && g->Wo == 4 && g->kh == 3 && g->kw == 3 &&
+                    g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->dh == 1 && g->dw == 1 && g->B % 8 == 0 && g->O % 16 == 0;
+#define KAN_BD3(KIND, FAST) \
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST, 1>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
+    if (fast == 1 && rb) KAN_BD3(KAN_BASIS_BSPLINE, 1);
+    else if (fast == 2 && rb) KAN_BD3(KAN_BASIS_BSPLINE, 2);
+    else if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2) KAN_BD2(KAN_BASIS_BSPLINE, 2);
     else if (fast == 3) KAN_BD2(KAN_BASIS_RBF, 3);
     else if (fast == 8) KAN_BD2(KAN_BASIS_RBF, 8);
@@ -3418,6 +3530,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     else if (b->kind == KAN_BASIS_RELU) KAN_BD(KAN_BASIS_RELU);
     else if (b->kind == KAN_BASIS_GRAM) KAN_BD(KAN_BASIS_GRAM);
     else KAN_BD(KAN_BASIS_CHEBY);
+#undef KAN_BD3
 #undef KAN_BD2
 #undef KAN_BD
     return launch_ok("conv_bwd_data");

@@ -2861,6 +2861,15 @@ FwdCfg fwd_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
     }
     return c;
 }
+// Row-ordered pixel blocks on 4x4 planes (k_conv_fwd_halo ROWBLK, k_conv_bwd_data RB): 1/6 of the MFMA blocks multiply the zero border and are skipped
+bool rowblk_fwd(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
+    return halo_fwd(g, b) && g->H == 4 && g->W == 4 && fwd_cfg(g, b, pl).TO == 256;
+}
+bool rowblk_bwd_data(const KanGeom* g, const KanBasis* b) {
+    const int f = fast_variant(b);
+    return !tuning_off("KAN_BD_ROWBLK") && (f == 1 || f == 2) && !want_pix_major(g, b, PM_BWD_DATA) && g->H == 4 && g->W == 4 && g->Ho == 4 && g->Wo == 4 &&
+           g->kh == 3 && g->kw == 3 && g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->dh == 1 && g->dw == 1 && g->B % 8 == 0 && g->O % 16 == 0;
+}
 // With dead-tap skipping the tiles of one launch carry 4/9 ... 9/9 of the nominal work depending on their pixel
 // position (or tap, for the weight gradient).  Each tile therefore gets its own split count ceil(live steps / target)
 // so that every workgroup runs ~`target` live steps, and the target is chosen on the host by the same round model as
@@ -3061,7 +3070,8 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     pl->fwd_halo = halo_fwd(g, b) ? 1 : 0;
     pl->bwd_weight_halo = halo_bwd_weight(g, b) ? 1 : 0;
-    pl->e_pm_wanted = 0; pl->fwd_expanded = 0; pl->bwd_weight_expanded = 0; pl->reserved = 0; pl->e_pm_elems = 0;
+    pl->e_pm_wanted = 0; pl->fwd_expanded = 0; pl->bwd_weight_expanded = 0; pl->e_pm_elems = 0;
+    pl->row_blocks = (rowblk_fwd(g, b, *pl) ? 1 : 0) | (rowblk_bwd_data(g, b) ? 2 : 0);
     if (dw_direct(g, b)) {
         pl->fwd_halo = pl->bwd_weight_halo = 0;                          // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
@@ -3509,8 +3519,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     const int fv = fast_variant(b);
     const int fast = (fv == 3 || fv == 8) ? ((x != xn && dxn) ? fv : 0) : ((x == xn && !dxn) ? fv : 0);
     // 4x4 planes in tiles of 8 whole images: row-ordered pixel blocks, dead (row, tap row) blocks skipped (see the kernel)
-    const bool rb = !dg.pix_major && !tuning_off("KAN_BD_ROWBLK") && g->H == 4 && g->W == 4 && g->Ho == 4 && g->Wo == 4 && g->kh == 3 && g->kw == 3 &&
-                    g->sh == 1 && g->sw == 1 && g->ph == 1 && g->pw == 1 && g->dh == 1 && g->dw == 1 && g->B % 8 == 0 && g->O % 16 == 0;
+    const bool rb = !dg.pix_major && rowblk_bwd_data(g, b);
 #define KAN_BD3(KIND, FAST) \
     hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST, 1>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
     if (fast == 1 && rb) KAN_BD3(KAN_BASIS_BSPLINE, 1);

@@ -165,6 +165,9 @@ def _executed_flops(geom, plan, which: str) -> float:
     target = {"fwd": plan.fwd_target, "bwd_data": plan.bwd_data_target, "bwd_weight": plan.bwd_weight_target}[which]
     dense = _conv_flops(geom, plan)
     if target <= 0:
+        # row-ordered 4x4 launches skip the blocks of the first / last row under the tap row that leaves the plane: 2/3 * 1/4 of the work
+        if plan.row_blocks & {"fwd": 1, "bwd_data": 2}.get(which, 0):
+            return dense * (5.0 / 6.0)
         return dense
     g = geom
     return dense * _live_fraction(which, g.H, g.W, g.Ho, g.Wo, g.kh, g.kw, g.sh, g.sw, g.ph, g.pw, g.dh, g.dw)

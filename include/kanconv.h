@@ -97,7 +97,9 @@ typedef struct KanPlan {
     int fwd_target, bwd_data_target, bwd_weight_target;   /* position-major launches: live steps per split (0 = n/a) */
     int x_pm_wanted, dz_pm_wanted;/* small padded planes: pass position-major copies (kan_position_major) of x / dz to
                                      unlock structural-zero tap skipping; optional, NULL keeps the image-major path */
-    int bwd_weight_expanded, reserved;   /* the weight gradient reads the expanded copy (kan_conv_bwd_weight_expanded) */
+    int bwd_weight_expanded;      /* the weight gradient reads the expanded copy (kan_conv_bwd_weight_expanded) */
+    int row_blocks;               /* informational: bit 0 / bit 1 = the forward / bwd-data launch orders 4x4 planes in row blocks and skips
+                                     the 1/6 of its MFMA work that multiplies the zero border */
     int e_pm_wanted, fwd_expanded;/* small padded planes: the weight gradient (and, with fwd_expanded, the forward) reads the EXPANDED
                                      position-major copy: build it with kan_position_major_expanded (e_pm_elems floats) and call
                                      kan_conv_bwd_weight_expanded / kan_conv_fwd_expanded */

@@ -346,12 +346,15 @@ def test_expanded_position_major_kernels_vs_oracle(C, O, H, B, G, gpu_lib):
     _compare(layer, _cfg("bspline", C, O, groups=G, act="silu"), torch.randn(B, C, H, H), tol_scale=8.0 if H == 2 else 2.0 if G > 1 else 1.0)
 
 
-@pytest.mark.parametrize("C,O,B,act", [(6, 256, 8, "silu"), (10, 256, 24, "gelu"), (4, 512, 16, "silu"), (6, 48, 8, "silu"), (6, 256, 12, "silu")],
+@pytest.mark.parametrize("C,O,B,act,want", [(6, 256, 8, "silu", 3), (10, 256, 24, "gelu", 3), (4, 512, 16, "silu", 3), (6, 48, 8, "silu", 2),
+                                              (6, 256, 12, "silu", 1)],
                          ids=["o256_b8", "o256_b24_gelu", "o512_b16", "o48_b8_bwd_only", "o256_b12_plain_bwd"])
-def test_row_block_kernels_on_4x4_planes_vs_oracle(C, O, B, act, gpu_lib):
+def test_row_block_kernels_on_4x4_planes_vs_oracle(C, O, B, act, want, gpu_lib):
     """4x4 planes: the halo forward (256-output tiles) and bwd-data (batch a multiple of 8, O a multiple of 16) order a tile's pixels
     (row, image, column) and skip the MFMA blocks of rows whose tap row lies outside the plane; bwd-data pairs tap rows 0 and 2 in
     mixed depth steps.  The last two cases take only one of the two kernels (O = 48: 64-output forward tiles; B = 12: plain bwd-data)."""
     torch.manual_seed(O + B)
+    from convkan_amd import ops
     layer = K.KANConv2DLayer(C, O, 3, padding=1, base_activation=nn.SiLU if act == "silu" else nn.GELU)
+    assert ops._plan_cached(layer.conv_spec(), B, C, 4, 4, O, C, O)[2].row_blocks == want      # bit 0: forward, bit 1: bwd-data
     _compare(layer, _cfg("bspline", C, O, act=act), torch.randn(B, C, 4, 4) * 1.5)

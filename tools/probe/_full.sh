@@ -1,0 +1,2 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/fin &&
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/fin/tests.txt 2>&1 ; tail -3 gpurun_out/fin/tests.txt

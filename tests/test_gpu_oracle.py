@@ -358,3 +358,13 @@ def test_row_block_kernels_on_4x4_planes_vs_oracle(C, O, B, act, want, gpu_lib):
     layer = K.KANConv2DLayer(C, O, 3, padding=1, base_activation=nn.SiLU if act == "silu" else nn.GELU)
     assert ops._plan_cached(layer.conv_spec(), B, C, 4, 4, O, C, O)[2].row_blocks == want      # bit 0: forward, bit 1: bwd-data
     _compare(layer, _cfg("bspline", C, O, act=act), torch.randn(B, C, 4, 4) * 1.5)
+
+
+def test_row_block_forward_for_the_recurrence_spec_vs_oracle(gpu_lib):
+    """The degree-3 recurrence spec (P = 5 planes) on the same row-ordered 4x4 forward (256-output halo tiles); its bwd-data stays plain."""
+    from convkan_amd import ops
+    torch.manual_seed(11)
+    layer = K.LucasKANConv2DLayer(6, 256, 3, degree=3, padding=1, base_activation=nn.SiLU)
+    plan = ops._plan_cached(layer.conv_spec(), 8, 6, 4, 4, 256, 6, 256)[2]
+    assert plan.fwd_halo == 1 and plan.row_blocks == 1
+    _compare(layer, _cfg("lucas", 6, 256, act="silu", degree=3), torch.randn(8, 6, 4, 4))

@@ -36,6 +36,13 @@ class KanPlan(C.Structure):
                                             "bwd_weight_slab_elems", "e_pm_elems")]
 
 
+class KanWavGeom(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "C", "H", "W", "O", "Ho", "Wo", "kh", "kw", "sh", "sw", "ph", "pw", "dh", "dw", "wavelet")] + \
+               [("x_bstride", C.c_longlong), ("u_bstride", C.c_longlong)]
+
+
+WAVELETS = {"mexican_hat": 0, "morlet": 1, "dog": 2, "meyer": 3, "shannon": 4}
+
 # every symbol include/kanconv.h declares, with its argument types
 _P, _I, _LL, _F, _D = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_double
 _GP, _BP = C.POINTER(KanGeom), C.POINTER(KanBasis)
@@ -59,6 +66,10 @@ SIGNATURES = {
     "kan_instnorm_prelu_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _LL, _I, _P]),
     "kan_instnorm_prelu_pool_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _F, _I, _P]),
     "kan_instnorm_prelu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _I, _P]),
+    "kan_wav_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(KanWavGeom), _P]),
+    "kan_wav_bwd_input": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(KanWavGeom), _P]),
+    "kan_wav_param_workspace": (_LL, [C.POINTER(KanWavGeom)]),
+    "kan_wav_bwd_params": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(KanWavGeom), _P]),
     "kan_adamw_step": (_I, [_P, _P, _P, _P, _LL, _D, _D, _D, _D, _D, _I, _F, _P]),
     "kan_adamw_step_segments": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _D, _D, _D, _D, _D, _I, _F, _P]),
 }

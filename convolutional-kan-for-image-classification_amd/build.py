@@ -8,7 +8,7 @@ import tempfile
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SOURCES = [os.path.join(_HERE, "csrc", "kanconv.hip")]
-HEADERS = [os.path.join(_HERE, "csrc", "kan_device.h"), os.path.join(_ROOT, "include", "kanconv.h")]
+HEADERS = [os.path.join(_HERE, "csrc", "kan_device.h"), os.path.join(_HERE, "csrc", "wavkan.inc"), os.path.join(_ROOT, "include", "kanconv.h")]
 OUTPUT = os.path.join(_HERE, "libkanconv.so")
 
 

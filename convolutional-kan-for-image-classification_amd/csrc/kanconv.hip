@@ -3245,6 +3245,9 @@ AdamArgs adam_args(double lr, double beta1, double beta2, double eps, double wei
     return a;
 }
 
+// ============================================================================ Wav-KAN wavelet stage (own C-ABI entry points inside)
+#include "wavkan.inc"
+
 }  // namespace
 
 // ============================================================================ C ABI

@@ -18,6 +18,8 @@ from .gram_layers import GRAMKANConv2DLayer
 from .poly_layers import (BersnsteinKANConv2DLayer, BesselKANConv2DLayer, FibonacciKANConv2DLayer, FourierKANConv2DLayer, LegendreKANConv2DLayer, GegenbauerKANConv2DLayer, HermiteKANConv2DLayer,
                           JacobiKANConv2DLayer, LaguerreKANConv2DLayer, LucasKANConv2DLayer, TaylorKANConv2DLayer)
 
+from .wav_layers import WavKANConv2DLayer
+
 _IntOrPair = Union[int, Tuple[int, int]]
 
 
@@ -240,6 +242,18 @@ def taylorkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, gro
 
 
 
+def wavkan_conv(in_planes: int, out_planes: int, kernel_size: _IntOrPair, groups: int = 1, stride: _IntOrPair = 1,
+                dilation: _IntOrPair = 1, padding: Optional[_IntOrPair] = None, l1_decay: float = 0.0, dropout: float = 0.0,
+                wavelet_type: str = 'mexican_hat', wav_version: str = 'fast',
+                norm_layer: Optional[Callable[..., nn.Module]] = nn.InstanceNorm2d, **norm_kwargs) -> WavKANConv2DLayer:
+    """kan_conv.py:278-318 (`l1_decay` travels into the layer's **norm_kwargs, where the norm-signature filter drops it)."""
+    if padding is None:
+        padding = _calculate_same_padding(kernel_size, dilation)
+    return _l1(l1_decay, WavKANConv2DLayer(input_dim=in_planes, output_dim=out_planes, kernel_size=kernel_size, stride=stride, padding=padding,
+                                           dilation=dilation, groups=groups, wavelet_type=wavelet_type, wav_version=wav_version, dropout=dropout,
+                                           l1_decay=l1_decay, norm_layer=norm_layer, **norm_kwargs))
+
+
 CONV_KAN_FACTORY = {
     "KAN": kan_conv,
     "FastKAN": fastkan_conv,
@@ -257,5 +271,6 @@ CONV_KAN_FACTORY = {
     "LucasKAN": lucaskan_conv,
     "ReLUKAN": relukan_conv,
     "TaylorKAN": taylorkan_conv,
+    "WavKAN": wavkan_conv,
     "conv": conv,
 }

@@ -308,7 +308,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
     x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
     _launch(("k_conv_fwd_halo/o" if plan.fwd_halo else "k_conv_fwd/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
             lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),
-                                     _ptr(x_pm), st), _executed_flops(geom, plan, "fwd") if x_pm is not None else None, _layer_tag(geom))
+                                     _ptr(x_pm), st), _executed_flops(geom, plan, "fwd") if (x_pm is not None or plan.row_blocks & 1) else None, _layer_tag(geom))
     return z, (wd, x_pm), geom, basis, plan
 
 
@@ -398,7 +398,7 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
                 lambda: lib.kan_conv_bwd_data(_ptr(dz), _ptr(x), _ptr(xs), _ptr(wd), _ptr(dxs), _ptr(dxns) if separate else C.c_void_p(0),
                                               C.byref(geom), C.byref(basis), _ptr(dz_pm), st),
-                _executed_flops(geom, plan, "bwd_data") if dz_pm is not None else None, _layer_tag(geom))
+                _executed_flops(geom, plan, "bwd_data") if (dz_pm is not None or plan.row_blocks & 2) else None, _layer_tag(geom))
         dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
     return dx, dxn, dw_base, dw_basis
 
@@ -645,6 +645,58 @@ class _InstanceNorm(torch.autograd.Function):
             L.check(lib.kan_instnorm_prelu_bwd(_ptr(dy), _ptr(x), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), C.c_void_p(0), _ptr(dx),
                                                _ptr(dg), _ptr(db), C.c_void_p(0), B, Cn, H * W, Cn * H * W, 0, _stream(x)), "kan_instnorm_prelu_bwd")
         return dx, dg, db, None
+
+
+# --------------------------------------------------------------------------------------- Wav-KAN wavelet stage
+class _WavStage(torch.autograd.Function):
+    """u = sum_{c, taps} w[o, c, tap] * psi((x - trans[o, c]) / scale[o, c]) for one group (wav_kan_layers.py:186-217 and the two
+    'fast' variants), on the direct kernels of csrc/wavkan.inc.  x: [B, C, H, W] contiguous; scale, trans: [O, C]; w: [O, C, kh, kw]."""
+
+    @staticmethod
+    def _geom(wavelet, x, w, stride, padding, dilation):
+        B, Cn, H, W = x.shape
+        O, _, kh, kw = w.shape
+        Ho = (H + 2 * padding[0] - dilation[0] * (kh - 1) - 1) // stride[0] + 1
+        Wo = (W + 2 * padding[1] - dilation[1] * (kw - 1) - 1) // stride[1] + 1
+        if Ho <= 0 or Wo <= 0:
+            raise L.KanConvError(f"empty output ({Ho}x{Wo}) for input {H}x{W}")
+        return L.KanWavGeom(B, Cn, H, W, O, Ho, Wo, kh, kw, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                            int(wavelet), Cn * H * W, O * Ho * Wo)
+
+    @staticmethod
+    def forward(ctx, wavelet, stride, padding, dilation, x, scale, trans, w):
+        lib = L.load()
+        x, scale, trans, w = (_require(t, n).contiguous() for t, n in ((x, "x"), (scale, "scale"), (trans, "translation"), (w, "wavelet weights")))
+        if scale.shape != (w.shape[0], w.shape[1]) or trans.shape != scale.shape or w.shape[1] != x.shape[1]:
+            raise L.KanConvError(f"wavelet parameter shapes {tuple(scale.shape)}, {tuple(trans.shape)}, {tuple(w.shape)} do not match input {tuple(x.shape)}")
+        geom = _WavStage._geom(wavelet, x, w, stride, padding, dilation)
+        u = torch.empty((geom.B, geom.O, geom.Ho, geom.Wo), device=x.device, dtype=torch.float32)
+        L.check(lib.kan_wav_fwd(_ptr(x), _ptr(scale), _ptr(trans), _ptr(w), _ptr(u), C.byref(geom), _stream(x)), "kan_wav_fwd")
+        ctx.save_for_backward(x, scale, trans, w)
+        ctx.geom = geom
+        return u
+
+    @staticmethod
+    def backward(ctx, du):
+        lib = L.load()
+        x, scale, trans, w = ctx.saved_tensors
+        geom = ctx.geom
+        du = du.contiguous()
+        st = _stream(x)
+        dx = dscale = dtrans = dw = None
+        if ctx.needs_input_grad[4]:
+            dx = torch.empty_like(x)
+            L.check(lib.kan_wav_bwd_input(_ptr(du), _ptr(x), _ptr(scale), _ptr(trans), _ptr(w), _ptr(dx), C.byref(geom), st), "kan_wav_bwd_input")
+        if any(ctx.needs_input_grad[5:8]):
+            ws = torch.empty((lib.kan_wav_param_workspace(C.byref(geom)),), device=x.device, dtype=torch.float32)
+            dw, dscale, dtrans = torch.empty_like(w), torch.empty_like(scale), torch.empty_like(trans)
+            L.check(lib.kan_wav_bwd_params(_ptr(du), _ptr(x), _ptr(scale), _ptr(trans), _ptr(w), _ptr(dw), _ptr(dscale), _ptr(dtrans), _ptr(ws),
+                                           C.byref(geom), st), "kan_wav_bwd_params")
+        return None, None, None, None, dx, dscale, dtrans, dw
+
+
+def wav_stage(wavelet: int, x: torch.Tensor, scale: torch.Tensor, trans: torch.Tensor, w: torch.Tensor, stride, padding, dilation) -> torch.Tensor:
+    return _WavStage.apply(int(wavelet), tuple(stride), tuple(padding), tuple(dilation), x, scale, trans, w)
 
 
 # --------------------------------------------------------------------------------------- public API

@@ -262,6 +262,28 @@ int kan_adamw_step_segments(float* p, float* m, float* v, const unsigned long lo
                             const int* chunk_seg, const int* chunk_start, const float* seg_bias, int n_chunks, int chunk_elems, double lr,
                             double beta1, double beta2, double eps, double weight_decay, int step, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------- Wav-KAN wavelet stage
+ * u[b, o, ho, wo] = sum_{c, r, t} w[o, c, r, t] * psi((x[b, c, hi, wi] - trans[o, c]) / scale[o, c]),  zero padding applied to the
+ * wavelet values.  Replaces WaveletConvND / WaveletConvNDFast / WaveletConvNDFastPlusOne .forward up to (not including) the 1x1
+ * `wavelet_out` conv (wav_kan_layers.py:186-217, 257-276, 318-338): the three versions are this arithmetic over differently shaped
+ * weight tensors.  One group per call (pre-offset x / u by the group's first channel; x_bstride / u_bstride = elements between
+ * images).  scale, trans: [O][C]; w: [O][C][kh][kw] (the 'fast' layout; 'base' and 'fast_plus_one' reshape to it).  fp32, direct
+ * vector-ALU kernels (every (o, c) pair has its own wavelet: nothing to share through a GEMM). */
+enum { KAN_WAV_MEXICAN_HAT = 0, KAN_WAV_MORLET = 1, KAN_WAV_DOG = 2, KAN_WAV_MEYER = 3, KAN_WAV_SHANNON = 4 };
+typedef struct {
+    int B, C, H, W, O, Ho, Wo, kh, kw, sh, sw, ph, pw, dh, dw;
+    int wavelet;                      /* KAN_WAV_* */
+    long long x_bstride, u_bstride;
+} KanWavGeom;
+int kan_wav_fwd(const float* x, const float* scale, const float* trans, const float* w, float* u, const KanWavGeom* geom, void* stream);
+/* dx = d loss / d x through the wavelets (autograd of the same lines); du: [B][O][Ho][Wo] with u_bstride */
+int kan_wav_bwd_input(const float* du, const float* x, const float* scale, const float* trans, const float* w, float* dx,
+                      const KanWavGeom* geom, void* stream);
+/* dw [O][C][kh][kw], dscale / dtrans [O][C]; workspace: kan_wav_param_workspace(geom) floats of scratch (partial sums, added in a fixed order) */
+long long kan_wav_param_workspace(const KanWavGeom* geom);
+int kan_wav_bwd_params(const float* du, const float* x, const float* scale, const float* trans, const float* w, float* dw, float* dscale,
+                       float* dtrans, float* workspace, const KanWavGeom* geom, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

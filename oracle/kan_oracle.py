@@ -364,6 +364,63 @@ def bersnsteinkan_conv2d(x: Tensor, w_base: Sequence[Tensor], poly_weights: Tens
 
 
 # --------------------------------------------------------------------------- whole-model oracle
+def wavelet(u: Tensor, kind: str, n_channels: int = 1) -> Tensor:
+    """The five wavelets of wav_kan_layers.py:145-190 on u = (x - translation) / scale, u: [B, O, C, H, W]."""
+    if kind == "mexican_hat":
+        return (2 / (math.sqrt(3) * math.pi ** 0.25)) * ((u ** 2) - 1) * torch.exp(-0.5 * u ** 2)
+    if kind == "morlet":
+        return torch.exp(-0.5 * u ** 2) * torch.cos(5.0 * u)
+    if kind == "dog":
+        return -u * torch.exp(-0.5 * u ** 2)
+    if kind == "meyer":
+        v = torch.abs(u)
+        nu = lambda t: t ** 4 * (35 - 84 * t + 70 * t ** 2 - 20 * t ** 3)
+        aux = torch.where(v <= 1 / 2, torch.ones_like(v), torch.where(v >= 1, torch.zeros_like(v), torch.cos(math.pi / 2 * nu(2 * v - 1))))
+        return torch.sin(math.pi * v) * aux
+    if kind == "shannon":                              # the Hamming window runs over the CHANNEL axis (x.size(2), wav_kan_layers.py:180-186)
+        window = torch.hamming_window(u.size(2), periodic=False, dtype=u.dtype, device=u.device).view(1, 1, -1, 1, 1)
+        return torch.sinc(u / math.pi) * window
+    raise ValueError(kind)
+
+
+def wavkan_conv2d(x: Tensor, w_base: Sequence[Tensor], scale: Sequence[Tensor], translation: Sequence[Tensor], w_wavelet: Sequence[Tensor],
+                  w_out: Sequence[Tensor], *, wavelet_type: str, stride=1, padding=0, dilation=1, groups: int = 1,
+                  norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
+    """norm(wavelet_out(sum_c conv(psi((x_c - t_oc) / s_oc), Wk[o, c])) + conv(SiLU(x), W_b))  (wav_kan_layers.py:430-443; the three
+    wavelet-conv versions, :186-217 / :257-276 / :318-338, are this sum over differently shaped weights).  scale / translation: per group
+    [1, O, C, 1, 1]; w_wavelet: per group [O, C, kh, kw]; w_out: per group [O, O, 1, 1]."""
+    def one(xg, g):
+        base = _conv(F.silu(xg), w_base[g], stride, padding, dilation)
+        psi = wavelet((xg.unsqueeze(1) - translation[g]) / scale[g], wavelet_type)           # [B, O, C, H, W]
+        O = psi.shape[1]
+        u = torch.cat([_conv(psi[:, o], w_wavelet[g][o:o + 1], stride, padding, dilation) for o in range(O)], dim=1)
+        z = F.conv2d(u, w_out[g]) + base
+        if pre_norm_out is not None:
+            pre_norm_out.append(z)
+        return F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)
+    return _per_group(x, groups, one)
+
+
+def wavkan_param_views(sd, groups: int, wav_version: str, ndim: int = 2):
+    """(w_base, scale, translation, w_wavelet [O, C, kh, kw], w_out [O, O, 1, 1]) per group from a WavKANConv{1,2}DLayer's named
+    parameters `sd` (wav_kan_layers.py:117-139 'base': one Conv(C -> 1) per output; :303-310 'fast': grouped conv [O, C, k, k]; :243-250
+    'fast_plus_one': Conv(N+1)D [O, 1, C, k, k]).  1-D layers are lifted to [.., 1, L] views."""
+    lift = (lambda t: t.unsqueeze(-2)) if ndim == 1 else (lambda t: t)
+    out = ([], [], [], [], [])
+    for g in range(groups):
+        pre = f"wavelet_conv.{g}."
+        if wav_version == "base":
+            n_out = sd[pre + "scale"].shape[1]
+            wk = torch.cat([sd[pre + f"wavelet_weights.{o}.weight"] for o in range(n_out)], dim=0)
+        elif wav_version == "fast":
+            wk = sd[pre + "wavelet_weights.weight"]
+        else:
+            wk = sd[pre + "wavelet_weights.weight"].squeeze(1)
+        for lst, t in zip(out, (sd[f"base_conv.{g}.weight"], sd[pre + "scale"], sd[pre + "translation"], wk, sd[pre + "wavelet_out.weight"])):
+            lst.append(lift(t))
+    return out
+
+
 VGG11_CFG = [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512]
 
 

@@ -214,6 +214,21 @@ HOSTACT_CASES = [
 ]
 
 
+# ---- Wav-KAN (wav_kan_layers.py): five wavelets, three weight layouts, per-(output, input) scale / translation moved off their 1 / 0 init
+WAV_CASES = [
+    C("wav", "tiny", 2, 3, 4, 8, 8, extra={"wavelet_type": "mexican_hat", "wav_version": "fast"}),
+    C("wav", "morlet_base_g2", 2, 4, 6, 7, 5, groups=2, xs=1.5, extra={"wavelet_type": "morlet", "wav_version": "base"}),
+    C("wav", "dog_plus1_s2_affine", 3, 4, 6, 9, 9, s=2, extra={"wavelet_type": "dog", "wav_version": "fast_plus_one"}, norm_kwargs={"affine": True}),
+    C("wav", "meyer_k5d2", 2, 3, 5, 11, 11, k=5, p=4, d=2, xs=0.7, extra={"wavelet_type": "meyer", "wav_version": "fast"}),
+    C("wav", "shannon_wide", 3, 12, 20, 6, 6, xs=2.0, extra={"wavelet_type": "shannon", "wav_version": "fast"}),
+    C("wav", "mexican_bn_p0", 3, 4, 8, 8, 8, p=0, norm="bn", extra={"wavelet_type": "mexican_hat", "wav_version": "fast"}),
+    C("wav", "dog_k1", 2, 5, 7, 6, 6, k=1, p=0, extra={"wavelet_type": "dog", "wav_version": "fast"}),
+    C("wav", "1d_morlet_s2", 2, 4, 6, 1, 33, ndim=1, s=2, extra={"wavelet_type": "morlet", "wav_version": "fast"}),
+    C("wav", "1d_mexican_plus1_g2", 2, 4, 6, 1, 21, ndim=1, groups=2, extra={"wavelet_type": "mexican_hat", "wav_version": "fast_plus_one"}),
+    C("wav", "small_planes", 8, 24, 40, 4, 4, extra={"wavelet_type": "mexican_hat", "wav_version": "fast"}),
+]
+
+
 def build_ref(c):
     kw = dict(kernel_size=c["k"], groups=c["groups"], padding=c["p"], stride=c["s"], dilation=c["d"])
     one_d = c.get("ndim", 2) == 1
@@ -222,6 +237,11 @@ def build_ref(c):
         if "norm" in c:
             kw["norm_layer"] = NORMS[c["norm"]]
         return REF_LAYERS.GRAMKANConv2DLayer(c["C"], c["O"], degree=c["degree"], **kw)
+    if c["kind"] == "wav":
+        kw.update(c.get("norm_kwargs", {}))
+        kw.update(c.get("extra", {}))
+        kw["norm_layer"] = (nn.BatchNorm1d if one_d else NORMS[c["norm"]]) if "norm" in c else (nn.InstanceNorm1d if one_d else nn.InstanceNorm2d)
+        return (REF_LAYERS.WavKANConv1DLayer if one_d else REF_LAYERS.WavKANConv2DLayer)(c["C"], c["O"], **kw)
     if c["kind"] == "relu":
         kw.update(c.get("norm_kwargs", {}))
         kw.update(c.get("extra", {}))
@@ -273,10 +293,26 @@ def build_ref(c):
 
 def oracle_forward(c, layer, x, pre):
     """Run the oracle with the reference layer's parameters."""
+    if c["kind"] == "wav":
+        return oracle_forward_wav(c, layer, x, pre)
     if c.get("ndim", 2) == 1:
         return oracle_forward_1d(c, layer, x, pre)
     return oracle_forward_2d(c, layer, dict(layer.named_parameters()), [layer.layer_norm[g] for g in range(c["groups"])],
                              dict(stride=c["s"], padding=c["p"], dilation=c["d"], groups=c["groups"]), x, pre)
+
+
+def oracle_forward_wav(c, layer, x, pre):
+    nd, G = c.get("ndim", 2), c["groups"]
+    wb, sc, tr, wk, wo = O.wavkan_param_views(dict(layer.named_parameters()), G, c["extra"]["wav_version"], nd)
+    if nd == 1:
+        norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(G)]
+        geo = dict(stride=(1, c["s"]), padding=(0, c["p"]), dilation=(1, c["d"]), groups=G)
+        pre4 = []
+        y = O.wavkan_conv2d(x.unsqueeze(2), wb, sc, tr, wk, wo, wavelet_type=c["extra"]["wavelet_type"], norm=norms, pre_norm_out=pre4, **geo)
+        pre.extend(p.squeeze(2) for p in pre4)
+        return y.squeeze(2)
+    return O.wavkan_conv2d(x, wb, sc, tr, wk, wo, wavelet_type=c["extra"]["wavelet_type"], norm=[layer.layer_norm[g] for g in range(G)],
+                           pre_norm_out=pre, stride=c["s"], padding=c["p"], dilation=c["d"], groups=G)
 
 
 def oracle_forward_1d(c, layer, x, pre):
@@ -346,6 +382,10 @@ def run_case(idx, c):
                 p.fill_(0.25 if j % 2 else 0.1)
             elif n == "beta_weights":                           # GRAM-KAN: O(0.1) recurrence coefficients instead of the ~1e-3 init
                 det_fill(p, idx * 31 + j, 0.25)
+            elif n.endswith(".scale"):                          # Wav-KAN: per-(output, input) dilations around 1, translations around 0
+                det_fill(p, idx * 31 + j, 0.3); p.add_(1.0)
+            elif n.endswith(".translation"):
+                det_fill(p, idx * 31 + j, 0.5)
             elif n.startswith("phase"):                         # ReLU-KAN phases: channels and planes drift apart as in training
                 d = torch.empty(p.shape); det_fill(d, idx * 31 + j, 0.07)      # (the reference's Parameter is an expand() view whose
                 p.data = p.data.clone() + d                                    #  channels alias one row: give it its own memory)
@@ -370,7 +410,7 @@ def run_case(idx, c):
 
     pre_ref = []
     hooks = []
-    if c["kind"] in ("bspline", "cheby", "relu", "gram") or c["kind"] in POLY_FAMILIES:
+    if c["kind"] in ("bspline", "cheby", "relu", "gram", "wav") or c["kind"] in POLY_FAMILIES:
         for g in range(c["groups"]):
             hooks.append(layer.layer_norm[g].register_forward_pre_hook(lambda m, a: pre_ref.append(a[0].detach().clone())))
     y = layer(x)
@@ -555,6 +595,12 @@ def hostact_cases():
         print(f"{c['kind']:10s} {c['name']:22s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
 
 
+def wav_cases():
+    for i, c in enumerate(WAV_CASES):
+        worst, sz = run_case(7400 + i, c)
+        print(f"{c['kind']:10s} {c['name']:22s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+
+
 def mlp_cases():
     for i, c in enumerate(MLP_CASES):
         worst, sz = run_mlp_case(i, c)
@@ -710,6 +756,8 @@ def main():
         return gram_cases()
     if "--3d-only" in sys.argv:
         return cases_3d()
+    if "--wav-only" in sys.argv:                    # Wav-KAN fixtures
+        return wav_cases()
     if "--hostact-only" in sys.argv:                # base activations the host applies
         return hostact_cases()
     if "--model-only" in sys.argv:                  # the two model fixtures + their tolerance calibration
@@ -727,6 +775,7 @@ def main():
     gram_cases()
     cases_3d()
     hostact_cases()
+    wav_cases()
     model_cases()
     print(f"total layer fixtures: {total / 1e6:.2f} MB")
 

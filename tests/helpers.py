@@ -31,6 +31,11 @@ def layer_kwargs(c):
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
         return kw
+    if c["kind"] == "wav":
+        one_d = c.get("ndim", 2) == 1
+        kw.update(c.get("extra", {}))
+        kw["norm_layer"] = (nn.BatchNorm1d if one_d else NORMS[c["norm"]]) if "norm" in c else (nn.InstanceNorm1d if one_d else nn.InstanceNorm2d)
+        return kw
     if c["kind"] == "gram":
         kw["degree"] = c["degree"]
         return kw
@@ -57,6 +62,8 @@ def layer_kwargs(c):
 
 def build_layer(c):
     import convkan_amd as K
+    if c["kind"] == "wav":
+        return (K.WavKANConv1DLayer if c.get("ndim", 2) == 1 else K.WavKANConv2DLayer)(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] == "gram":
         return K.GRAMKANConv2DLayer(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] == "relu":
@@ -82,6 +89,20 @@ def relerr(a, b):
 def oracle_forward(c, layer, x, pre=None):
     """Oracle forward with `layer`'s parameters (any object exposing the reference's attribute names)."""
     G = c["groups"]
+    if c["kind"] == "wav":
+        from oracle import kan_oracle as O
+        nd = c.get("ndim", 2)
+        wb, sc, tr, wk, wo = O.wavkan_param_views(dict(layer.named_parameters()), G, c["extra"]["wav_version"], nd)
+        if nd == 1:
+            norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(G)]
+            pre4 = [] if pre is not None else None
+            y = O.wavkan_conv2d(x.unsqueeze(2), wb, sc, tr, wk, wo, wavelet_type=c["extra"]["wavelet_type"], norm=norms, pre_norm_out=pre4,
+                                stride=(1, c["s"]), padding=(0, c["p"]), dilation=(1, c["d"]), groups=G)
+            if pre is not None:
+                pre.extend(p.squeeze(2) for p in pre4)
+            return y.squeeze(2)
+        return O.wavkan_conv2d(x, wb, sc, tr, wk, wo, wavelet_type=c["extra"]["wavelet_type"], norm=[layer.layer_norm[g] for g in range(G)],
+                               pre_norm_out=pre, stride=c["s"], padding=c["p"], dilation=c["d"], groups=G)
     if c.get("ndim", 2) == 1:          # 1-D layer == the 2-D oracle on [B, C, 1, L] with (1, k) kernels
         sd = {n: p.unsqueeze(-1) if n.startswith("phase") else p.unsqueeze(2) if p.dim() == 3 else p for n, p in layer.named_parameters()}
         norms = [(lambda z, m=layer.layer_norm[g]: m(z.squeeze(2)).unsqueeze(2)) for g in range(G)]

@@ -176,7 +176,17 @@ def test_polynomial_family_surface():
 def test_factory_signatures_and_same_padding():
     F = K.CONV_KAN_FACTORY
     poly = {"BesselKAN", "FibonacciKAN", "GegenbauerKAN", "HermiteKAN", "JacobiKAN", "LaguerreKAN", "LucasKAN", "TaylorKAN"}
-    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "ReLUKAN", "GRAMKAN", "conv"} | poly
+    assert set(F) == {"KAN", "FastKAN", "ChebyKAN", "FourierKAN", "LegendreKAN", "BersnsteinKAN", "ReLUKAN", "GRAMKAN", "WavKAN", "conv"} | poly      # kan_conv.py:726-745: all 18
+    wv = F["WavKAN"](4, 6, 3, groups=2)                          # kan_conv.py:278-318: 'fast' wavelet conv, InstanceNorm2d, same padding
+    assert wv.padding == 1 and wv.wavelet_type == "mexican_hat" and type(wv.wavelet_conv[0]).__name__ == "WaveletConvNDFast"
+    assert isinstance(wv.layer_norm[0], nn.InstanceNorm2d) and isinstance(wv.base_activation, nn.SiLU)
+    assert list(wv.state_dict()) == ["base_conv.0.weight", "base_conv.1.weight", "wavelet_conv.0.scale", "wavelet_conv.0.translation",
+                                     "wavelet_conv.0.wavelet_weights.weight", "wavelet_conv.0.wavelet_out.weight", "wavelet_conv.1.scale",
+                                     "wavelet_conv.1.translation", "wavelet_conv.1.wavelet_weights.weight", "wavelet_conv.1.wavelet_out.weight"]
+    assert wv.wavelet_conv[0].scale.shape == (1, 3, 2, 1, 1) and wv.wavelet_conv[0].wavelet_weights.weight.shape == (3, 2, 3, 3)
+    assert K.WavKANConv2DLayer(4, 6, 3, wav_version="fast_plus_one").wavelet_conv[0].wavelet_weights.weight.shape == (6, 1, 4, 3, 3)
+    assert len(K.WavKANConv2DLayer(4, 6, 3, wav_version="base").wavelet_conv[0].wavelet_weights) == 6
+    assert isinstance(K.WavKANConv2DLayer(4, 6, 3).layer_norm[0], nn.BatchNorm2d)       # the class default (wav_kan_layers.py:467)
     gr = F["GRAMKAN"](4, 6, 3, groups=2, dilation=2)            # kan_conv.py:158-194; gram_kan_layers.py:85-148
     assert (gr.padding, gr.dilation, gr.degree) == (2, 2, 3) and isinstance(gr.base_activation, nn.SiLU)
     assert list(gr.state_dict()) == ["poly_weights", "beta_weights", "base_conv.0.weight", "base_conv.1.weight"]

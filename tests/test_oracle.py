@@ -28,6 +28,9 @@ class _Params(nn.Module):
             if n in ("base_conv", "spline_conv", "poly_conv", "fourier_conv", "relukan_conv", "prelus"):
                 lst = nn.ParameterList([nn.Parameter(torch.from_numpy(d[f"sd.{n}.{g}.weight"])) for g in range(G)])
                 setattr(self, n + "_p", lst)
+        if c["kind"] == "wav":                                    # Wav-KAN: nested module names, kept verbatim
+            self._wav_names = [k[3:] for k in d if k.startswith("sd.") and not k.startswith("sd.layer_norm")]
+            self._wav_params = nn.ParameterList([nn.Parameter(torch.from_numpy(d["sd." + n])) for n in self._wav_names])
         if "sd.poly_weights" in d:                                # JacobiKAN: one [G, O/G, C/G*(deg+1), k, k] parameter
             self.poly_weights = nn.Parameter(torch.from_numpy(d["sd.poly_weights"]))
             self.a, self.b = c.get("extra", {}).get("a"), c.get("extra", {}).get("b")
@@ -48,7 +51,10 @@ class _Params(nn.Module):
 
     def named_parameters(self, *a, **k):       # names as in the reference's state_dict
         for n, p in super().named_parameters(*a, **k):
-            yield (n.replace("_p.", ".") + ".weight" if "_p." in n else n), p
+            if n.startswith("_wav_params."):
+                yield self._wav_names[int(n.split(".")[1])], p
+            else:
+                yield (n.replace("_p.", ".") + ".weight" if "_p." in n else n), p
 
 
 @pytest.mark.parametrize("name", golden_cases())

@@ -143,6 +143,11 @@ class WavKANConvNDLayer(_HipLayer):
         return ops.ConvSpec(kind=L.BASIS_POLY, n_basis=1, order=0, act=act, p0=0.0, p1=0.0, table=(1.0, 0.0, 0.0),
                             kernel=kernel, stride=stride, padding=padding, dilation=dilation, groups=self.groups)
 
+    def conv_spec(self) -> ops.ConvSpec:
+        """Spec of the base-conv launch (geometry queries: out_hw)."""
+        wc0 = self.wavelet_conv[0]
+        return self._const_plane_spec(L.ACT_SILU, wc0._ks, wc0._st, wc0._pd, wc0._dl)
+
     def forward(self, x):
         G, og = self.groups, self.output_dim_group
         cg = self.inputdim // G

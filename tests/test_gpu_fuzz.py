@@ -277,3 +277,36 @@ def test_parametric_families_on_expanded_position_major_kernels(fam, H, B, gpu_l
             layer.beta_weights.normal_(0.0, 0.2)
     cfg = _cfg("relu" if fam == "ReLUKAN" else "gram", C, O, k=3, s=1, p=1, d=1, groups=1, degree=3, extra={}, act="silu")
     _check(layer, cfg, torch.randn(B, C, H, H) * 1.5, dict(fam=fam, C=C, O=O, G=1, H=H, W=H, B=B, affine=False))
+
+
+@pytest.mark.parametrize("seed", range(_OFF, _OFF + int(__import__("os").environ.get("KAN_FUZZ_WAV_N", "40"))))
+def test_random_wavkan_vs_oracle(seed, gpu_lib):
+    """Wav-KAN over random geometries, the five wavelets and the three weight layouts, scale / translation off their 1 / 0 init."""
+    r = random.Random(12000 + seed)
+    wavelet = ["mexican_hat", "morlet", "dog", "meyer", "shannon"][seed % 5]
+    version = ["fast", "base", "fast_plus_one"][(seed // 5) % 3]
+    G = r.choice([1, 1, 2, 3])
+    C, O = r.choice([1, 2, 3, 5, 16]) * G, r.choice([1, 3, 4, 6, 33]) * G
+    kk = r.choice([1, 3, 3, 5, (3, 1), (1, 3)])
+    kh, kw = (kk, kk) if isinstance(kk, int) else kk
+    s_, d, p = r.choice([1, 1, 2]), r.choice([1, 1, 2]), r.choice([0, 1, 2])
+    H, W = r.choice([(4, 4), (8, 8), (16, 16), (5, 7), (9, 4), (32, 32), (20, 12)])
+    if (H + 2 * p - d * (kh - 1) - 1) // s_ + 1 <= 0 or (W + 2 * p - d * (kw - 1) - 1) // s_ + 1 <= 0:
+        p = d * (max(kh, kw) - 1)
+    ho, wo = (H + 2 * p - d * (kh - 1) - 1) // s_ + 1, (W + 2 * p - d * (kw - 1) - 1) // s_ + 1
+    if ho * wo < 4:
+        s_, d, p = 1, 1, max(p, max(kh, kw) // 2)
+    B = r.choice([1, 2, 3, 9, 20])
+    affine = r.random() < 0.4
+    torch.manual_seed(seed)
+    layer = K.WavKANConv2DLayer(C, O, kk, groups=G, stride=s_, dilation=d, padding=p, wavelet_type=wavelet, wav_version=version,
+                                norm_layer=nn.InstanceNorm2d, affine=affine)
+    with torch.no_grad():
+        for m in layer.wavelet_conv:
+            m.scale.add_(0.3 * (torch.rand_like(m.scale) - 0.5)); m.translation.add_(0.5 * torch.randn_like(m.translation))
+        if affine:
+            for m in layer.layer_norm:
+                m.weight.add_(0.2 * torch.randn_like(m.weight)); m.bias.add_(0.2 * torch.randn_like(m.bias))
+    cfg = _cfg("wav", C, O, k=kk, s=s_, p=p, d=d, groups=G, extra=dict(wavelet_type=wavelet, wav_version=version))
+    x = torch.randn(B, C, H, W) * (0.7 + (seed % 3))
+    _check(layer, cfg, x, dict(fam="WavKAN", wavelet=wavelet, version=version, C=C, O=O, G=G, k=kk, s=s_, d=d, p=p, H=H, W=W, B=B, affine=affine))

@@ -130,13 +130,14 @@ def test_random_geometry_vs_oracle(seed, gpu_lib):
 ALL_FAMILIES = {"KAN": "bspline", "FastKAN": "rbf", "ChebyKAN": "cheby", "BesselKAN": "bessel", "FibonacciKAN": "fibonacci",
                 "GegenbauerKAN": "gegenbauer", "HermiteKAN": "hermite", "JacobiKAN": "jacobi", "LaguerreKAN": "laguerre",
                 "LucasKAN": "lucas", "TaylorKAN": "taylor", "FourierKAN": "fourier", "LegendreKAN": "legendre",
-                "BersnsteinKAN": "bersnstein", "ReLUKAN": "relu", "GRAMKAN": "gram"}
-EXTRA = {"gegenbauer": {"alpha_param": 0.0}, "laguerre": {"alpha": 1.0}, "jacobi": {"a": 1.0, "b": 1.0}}
+                "BersnsteinKAN": "bersnstein", "ReLUKAN": "relu", "GRAMKAN": "gram", "WavKAN": "wav"}
+EXTRA = {"gegenbauer": {"alpha_param": 0.0}, "laguerre": {"alpha": 1.0}, "jacobi": {"a": 1.0, "b": 1.0},
+         "wav": {"wavelet_type": "mexican_hat", "wav_version": "fast"}}
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KAN_FUZZ_FAM_N", "42"))))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("KAN_FUZZ_FAM_N", "51"))))
 def test_random_family_vs_oracle(seed, gpu_lib):
-    """Every registered conv-KAN family (16 factory keys) on 3x3 'same' layers over the plane sizes and widths of the model zoo (incl. the
+    """Every registered conv-KAN family (all 17 factory keys besides plain `conv`) on 3x3 'same' layers over the plane sizes and widths of the model zoo (incl. the
     halo / 256-output-tile / position-major paths), affine or plain InstanceNorm."""
     r = random.Random(5000 + seed)
     fam = list(ALL_FAMILIES)[seed % len(ALL_FAMILIES)]

@@ -451,7 +451,9 @@ __global__ __launch_bounds__(256) void k_position_major(const float* __restrict_
 //   4 / 5 : Chebyshev degree 4 / 3, no base branch                                P = 5 / 4
 //   9     : ReLU-KAN g = 5, k = 3 (8 planes) + base branch SiLU, phases in device memory  P = 9   (halo kernels only)
 //   10    : GRAM-KAN degree 3 (4 planes) + base branch, SiLU, coefficients in device memory  P = 5   (halo kernels only)
-__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6 || fast == 10) ? 5 : (fast == 5 || fast == 7) ? 4 : fast == 8 ? 6 : 9; }
+//   11    : a base branch + ONE constant polynomial plane (degree-0 recurrence)  P = 2   -- with zero weights on the constant plane this is a plain
+//           convolution of act(x): Wav-KAN's base conv and 1x1 `wavelet_out` conv (layers/wav_layers.py), Bessel/Taylor/... at degree 0
+__host__ __device__ constexpr int fast_planes(int fast) { return (fast == 4 || fast == 6 || fast == 10) ? 5 : (fast == 5 || fast == 7) ? 4 : fast == 8 ? 6 : fast == 11 ? 2 : 9; }
 __device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f)); }
 
 template <int KIND, int FAST>
@@ -500,6 +502,11 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
             col[(1 + k) * ld] = inb ? Tc : 0.f;
             if (k + 1 < NB) { const float Tn = (bs.tab[3 * k] * t + bs.tab[3 * k + 1]) * Tc + bs.tab[3 * k + 2] * Tm; Tm = Tc; Tc = Tn; }
         }
+        return;
+    }
+    if (KIND == KAN_BASIS_POLY && FAST == 11) {
+        col[0] = inb ? (bs.act == KAN_ACT_SILU ? silu_fast(xa) : kan_act(bs.act, xa)) : 0.f;
+        col[ld] = inb ? bs.tab[0] : 0.f;
         return;
     }
     if (KIND == KAN_BASIS_RELU && FAST == 9) {
@@ -1296,10 +1303,10 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
         }
         return;
     }
-    if (FAST == 6 || FAST == 7) {
-        // Recurrence families, degree 3 with a base branch (P = 5 / 4, CH = 12 / 16 channels per half), single input
+    if (FAST == 6 || FAST == 7 || FAST == 11) {
+        // Recurrence families, degree 3 (or 0: FAST 11, one constant plane, no polynomial derivative) with a base branch (P = 5 / 4 / 2, CH = 12 / 16 / 32 channels per half), single input
         // tensor: x prefetched, derivative by the differentiated recurrence with compile-time plane count.
-        constexpr int FP = FAST == 6 ? 5 : 4, NB = FP - 1, FCH = 64 / FP, NIT = (FCH + 1) / 2;
+        constexpr int FP = FAST == 6 ? 5 : FAST == 7 ? 4 : 2, NB = FP - 1, FCH = 64 / FP, NIT = (FCH + 1) / 2;
         float xv[2][NIT]; unsigned ok = 0;
 #pragma unroll
         for (int half = 0; half < 2; ++half)
@@ -3112,7 +3119,7 @@ int fast_variant(const KanBasis* b) {
     if (b->kind == KAN_BASIS_BSPLINE && b->n_basis == 8 && b->order == 3) return b->act == KAN_ACT_SILU ? 1 : b->act == KAN_ACT_GELU ? 2 : 0;
     if (b->kind == KAN_BASIS_RBF && b->act == KAN_ACT_SILU && (b->n_basis == 8 || b->n_basis == 5)) return b->n_basis == 8 ? 3 : 8;
     if (b->kind == KAN_BASIS_CHEBY && b->act == KAN_ACT_NONE) return b->n_basis == 5 ? 4 : b->n_basis == 4 ? 5 : 0;
-    if (b->kind == KAN_BASIS_POLY && b->act != KAN_ACT_NONE) return b->n_basis == 4 ? 6 : b->n_basis == 3 ? 7 : 0;
+    if (b->kind == KAN_BASIS_POLY && b->act != KAN_ACT_NONE) return b->n_basis == 4 ? 6 : b->n_basis == 3 ? 7 : b->n_basis == 1 ? 11 : 0;
     if (b->kind == KAN_BASIS_RELU && b->act == KAN_ACT_SILU && b->n_basis == 8) return 9;      // halo kernels only
     if (b->kind == KAN_BASIS_GRAM && b->act == KAN_ACT_SILU && b->n_basis == 4) return 10;     // halo kernels only
     return 0;
@@ -3460,6 +3467,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     else if (fast == 5) KAN_FWD_FAST(KAN_BASIS_CHEBY, 5, 16);
     else if (fast == 6) KAN_FWD_FAST(KAN_BASIS_POLY, 6, 16);
     else if (fast == 7) KAN_FWD_FAST(KAN_BASIS_POLY, 7, 16);
+    else if (fast == 11) KAN_FWD_FAST(KAN_BASIS_POLY, 11, 16);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_FWD_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_FWD_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_FWD_KIND(KAN_BASIS_POLY);
@@ -3535,6 +3543,7 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     else if (fast == 5) KAN_BD2(KAN_BASIS_CHEBY, 5);
     else if (fast == 6) KAN_BD2(KAN_BASIS_POLY, 6);
     else if (fast == 7) KAN_BD2(KAN_BASIS_POLY, 7);
+    else if (fast == 11) KAN_BD2(KAN_BASIS_POLY, 11);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BD(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BD(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BD(KAN_BASIS_POLY);
@@ -3624,6 +3633,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
     else if (fast == 5) KAN_BW_FAST(KAN_BASIS_CHEBY, 5);
     else if (fast == 6) KAN_BW_FAST(KAN_BASIS_POLY, 6);
     else if (fast == 7) KAN_BW_FAST(KAN_BASIS_POLY, 7);
+    else if (fast == 11) KAN_BW_FAST(KAN_BASIS_POLY, 11);
     else if (b->kind == KAN_BASIS_BSPLINE) KAN_BW_KIND(KAN_BASIS_BSPLINE);
     else if (b->kind == KAN_BASIS_RBF) KAN_BW_KIND(KAN_BASIS_RBF);
     else if (b->kind == KAN_BASIS_POLY) KAN_BW_KIND(KAN_BASIS_POLY);

@@ -368,3 +368,14 @@ def test_row_block_forward_for_the_recurrence_spec_vs_oracle(gpu_lib):
     plan = ops._plan_cached(layer.conv_spec(), 8, 6, 4, 4, 256, 6, 256)[2]
     assert plan.fwd_halo == 1 and plan.row_blocks == 1
     _compare(layer, _cfg("lucas", 6, 256, act="silu", degree=3), torch.randn(8, 6, 4, 4))
+
+
+@pytest.mark.parametrize("C,O,H,B,G,act", [(6, 32, 8, 4, 1, "silu"), (8, 128, 4, 16, 1, "gelu"), (4, 256, 16, 2, 1, "silu"), (8, 64, 2, 32, 2, "silu"), (3, 8, 7, 3, 1, "none")],
+                         ids=["8x8", "4x4_o128", "16x16_o256", "2x2_groups2", "identity_7x7"])
+def test_constant_plane_spec_vs_oracle(C, O, H, B, G, act, gpu_lib):
+    """A recurrence family at degree 0 = base branch + ONE constant plane (the compile-time two-plane spec that also carries Wav-KAN's plain
+    convolutions); `act='none'` leaves the generic kernels (no base branch)."""
+    torch.manual_seed(C * O + H)
+    acts = {"silu": nn.SiLU, "gelu": nn.GELU, "none": None}
+    layer = K.BesselKANConv2DLayer(C, O, 3, degree=0, padding=1, groups=G, base_activation=acts[act])
+    _compare(layer, _cfg("bessel", C, O, groups=G, act=act, degree=0), torch.randn(B, C, H, H), tol_scale=8.0 if H == 2 else 1.0)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "kan_conv_fwd": (_I, [_P, _P, _P, _P, _GP, _BP, _P, _P]),
     "kan_position_major": (_I, [_P, _P, _I, _I, _I, _LL, _P]),
     "kan_conv_bwd_data": (_I, [_P, _P, _P, _P, _P, _P, _GP, _BP, _P, _P]),
+    "kan_conv_bwd_data_params": (_I, [_P, _P, _P, _P, _P, _P, _P, _GP, _BP, _P, _P]),
     "kan_conv_bwd_weight": (_I, [_P, _P, _P, _P, _GP, _BP, _P, _P, _P]),
     "kan_position_major_expanded": (_I, [_P, _P, _GP, _BP, _P]),
     "kan_conv_fwd_expanded": (_I, [_P, _P, _P, _GP, _BP, _P]),

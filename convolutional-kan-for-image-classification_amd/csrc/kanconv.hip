@@ -1016,7 +1016,7 @@ template <int KIND, int FAST, int RB = 0>
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, const float* __restrict__ wd,
     float* __restrict__ dx, float* __restrict__ dxn, DevGeom g, DevBasis bs, int CH, int n_ct, int n_ob, int Opad16,
-    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes, TilePerm perm) {     // grid.y = groups * n_ct
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned dz_bytes, TilePerm perm, float* __restrict__ dpar) {     // grid.y = groups * n_ct
     constexpr int TP = 128, KD = 16, NT = 256;
     __shared__ __attribute__((aligned(16))) float smem[2 * 2 * KD * 128];   // 2 x (sW 16x128 + sG 16x128) = 32 KB; epilogue 64x128
     __shared__ float sTab[KAN_MAX_TABLE];
@@ -1452,6 +1452,67 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
             }
             if (split_out) { dxs[idx] = s_base; dxns[idx] = s_bas; }
             else dxs[idx] = s_base + s_bas;
+        }
+        if (KIND == KAN_BASIS_GRAM && dpar) {
+            // GRAM-KAN: d loss / d c_{m+1} = sum over channels and pixels of sum_k act'(P_k) dP_k/dc_{m+1} G_{c,k} (gram_kan_layers.py:156-182), from
+            // the same G tile.  The coefficients are layer-global, so every workgroup would hit the same few words: a thread sums over its
+            // channels, the wave adds up, and lane 0 adds to one of 64 slot rows dpar[slot][n] (the host sums the rows).
+            const int nb = bs.nb;
+            float am[KAN_PMAX];
+#pragma unroll
+            for (int m = 0; m < KAN_PMAX; ++m) am[m] = 0.f;
+            for (int cl = ol0; cl < CH; cl += 2) {
+                const int c = (ct * 2 + half) * CH + cl;
+                if (c >= g.C) continue;
+                const float xb = pv ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
+#pragma unroll
+                for (int m = 1; m < KAN_PMAX - 1; ++m) {
+                    if (m < nb - 1) {                                              // modes 1 .. nb - 2: derivative w.r.t. c_{m+1}
+                        DevBasis bm = bs; bm.order = m;
+                        float v[KAN_PMAX];
+                        kan_planes<KAN_BASIS_GRAM, false>(bm, sTab, xb, xb, v, c);
+                        float sacc = 0.f;
+#pragma unroll
+                        for (int p = 0; p < KAN_PMAX; ++p)
+                            if (p < P) sacc += v[p] * smem[(cl * P + p) * TP + pxl];
+                        am[m] += pv ? sacc : 0.f;
+                    }
+                }
+            }
+            const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & 63u;
+#pragma unroll
+            for (int m = 1; m < KAN_PMAX - 1; ++m) {
+                if (m < nb - 1) {
+                    float v = am[m];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                    if (lane == 0) atomicAdd(dpar + (size_t)slot * nb + m + 1, v);
+                }
+            }
+        }
+        if (KIND == KAN_BASIS_RELU && dpar) {
+            // Phase gradients of ReLU-KAN from the same G tile: d loss / d lo[c][j] = sum_pixels d plane_j / d lo * G_{c,j} (likewise hi) -- what two
+            // more runs of the weight-gradient kernel on the parameter-derivative planes would deliver (relu_kan_layers.py:127-131).  G of a split is
+            // a partial sum over its (tap, output) range and the gradient is linear in it, so every split adds its share.  Per channel: each lane
+            // forms its pixel's 2 n products, the wave adds them up (xor shuffles), lane 0 adds the sums to dpar[c][2][n] (float atomics: these are
+            // per-channel scalars like d gamma; the data path stays atomic-free).
+            const int nb = bs.nb, hb = bs.hb;
+            const float rr = bs.p0;
+            for (int cl = ol0; cl < CH; cl += 2) {                                  // (wave-uniform)
+                const int c = (ct * 2 + half) * CH + cl;
+                if (c >= g.C) continue;
+                const float xb = pv ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
+                const float* lo = bs.ctab + (size_t)c * 2 * nb;
+                for (int j = 0; j < nb; ++j) {
+                    const float gv = pv ? smem[(cl * P + hb + j) * TP + pxl] : 0.f;
+                    const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(lo[nb + j] - xb, 0.f);
+                    const float q2 = 2.0f * (x1 * x2 * rr) * rr;
+                    float vlo = -(q2 * x2) * gv, vhi = (q2 * x1) * gv;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) { vlo += __shfl_xor(vlo, off, 64); vhi += __shfl_xor(vhi, off, 64); }
+                    if (lane == 0) { atomicAdd(dpar + (size_t)c * 2 * nb + j, vlo); atomicAdd(dpar + (size_t)c * 2 * nb + nb + j, vhi); }
+                }
+            }
         }
     }
 }
@@ -3482,8 +3543,24 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
     return launch_ok("conv_fwd");
 }
 
+static int conv_bwd_data_impl(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn, float* dpar,
+                              const KanGeom* g, const KanBasis* b, const float* dz_pm, void* stream);
+
 int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn,
                       const KanGeom* g, const KanBasis* b, const float* dz_pm, void* stream) {
+    return conv_bwd_data_impl(dz, x, xn, wd, dx, dxn, nullptr, g, b, dz_pm, stream);
+}
+
+int kan_conv_bwd_data_params(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn, float* dparams,
+                             const KanGeom* g, const KanBasis* b, const float* dz_pm, void* stream) {
+    if (!dparams) return fail("null dparams");
+    if (b && b->kind != KAN_BASIS_RELU && b->kind != KAN_BASIS_GRAM) return fail("kan_conv_bwd_data_params: only the ReLU-KAN and GRAM bases accumulate parameter gradients in this launch");
+    if (g && b && dw_direct(g, b)) return fail("kan_conv_bwd_data_params: depthwise layers take the weight-gradient route");
+    return conv_bwd_data_impl(dz, x, xn, wd, dx, dxn, dparams, g, b, dz_pm, stream);
+}
+
+static int conv_bwd_data_impl(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn, float* dpar,
+                              const KanGeom* g, const KanBasis* b, const float* dz_pm, void* stream) {
     KanPlan pl;
     if (int rc = make_plan(g, b, &pl)) return rc;
     if (!dz || !x || !xn || !wd || !dx) return fail("null tensor pointer");
@@ -3525,14 +3602,14 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
     }
 #define KAN_BD(KIND) KAN_BD2(KIND, 0)
 #define KAN_BD2(KIND, FAST) \
-    hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm, dpar)
     // compile-time epilogues: single-input specs need x == xn and one output; the FastKAN specs need both tensors
     const int fv = fast_variant(b);
     const int fast = (fv == 3 || fv == 8) ? ((x != xn && dxn) ? fv : 0) : ((x == xn && !dxn) ? fv : 0);
     // 4x4 planes in tiles of 8 whole images: row-ordered pixel blocks, dead (row, tap row) blocks skipped (see the kernel)
     const bool rb = !dg.pix_major && rowblk_bwd_data(g, b);
 #define KAN_BD3(KIND, FAST) \
-    hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST, 1>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm)
+    hipLaunchKernelGGL((k_conv_bwd_data<KIND, FAST, 1>), grid, dim3(256), 0, st, dz, x, xn, wd, dx, dxn, dg, db, c.CH, c.tiles_c, c.n_ob, c.Opad32, c.chunks, cps, pl.bwd_data_slab_elems, (unsigned)((long long)g->B * g->y_bstride * 4), perm, dpar)
     if (fast == 1 && rb) KAN_BD3(KAN_BASIS_BSPLINE, 1);
     else if (fast == 2 && rb) KAN_BD3(KAN_BASIS_BSPLINE, 2);
     else if (fast == 1) KAN_BD2(KAN_BASIS_BSPLINE, 1);

@@ -349,7 +349,7 @@ def _sink_for(wid, shape, device):
     return t
 
 
-def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool, phases=None, mode: int = 0, wids=None):
+def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: bool, need_w: bool, phases=None, mode: int = 0, wids=None, dparams=None):
     """dz: [B,O,Ho,Wo] contiguous.  Returns (dx, dxn, dw_base list, dw_basis list) -- per-group views of stacked gradients.
     `wids`: ids of the (base, basis) weight Parameters of a single-group layer, for GRAD_SINKS."""
     lib = L.load()
@@ -396,8 +396,10 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
         dxs = torch.empty((S, B, Ct, H, W), device=x.device, dtype=torch.float32)
         dxns = torch.empty_like(dxs) if separate else None
         _launch("k_conv_bwd_data", _conv_flops(geom, plan), x,
-                lambda: lib.kan_conv_bwd_data(_ptr(dz), _ptr(x), _ptr(xs), _ptr(wd), _ptr(dxs), _ptr(dxns) if separate else C.c_void_p(0),
-                                              C.byref(geom), C.byref(basis), _ptr(dz_pm), st),
+                (lambda: lib.kan_conv_bwd_data(_ptr(dz), _ptr(x), _ptr(xs), _ptr(wd), _ptr(dxs), _ptr(dxns) if separate else C.c_void_p(0),
+                                               C.byref(geom), C.byref(basis), _ptr(dz_pm), st)) if dparams is None else
+                (lambda: lib.kan_conv_bwd_data_params(_ptr(dz), _ptr(x), _ptr(xs), _ptr(wd), _ptr(dxs), _ptr(dxns) if separate else C.c_void_p(0),
+                                                      _ptr(dparams), C.byref(geom), C.byref(basis), _ptr(dz_pm), st)),
                 _executed_flops(geom, plan, "bwd_data") if (dz_pm is not None or plan.row_blocks & 2) else None, _layer_tag(geom))
         dx, dxn = _sum_slabs(dxs, B, Ct, H * W), (_sum_slabs(dxns, B, Ct, H * W) if separate else None)
     return dx, dxn, dw_base, dw_basis
@@ -456,6 +458,11 @@ class _KanConv(torch.autograd.Function):
         return (None, dx if need_x else None, dxn if need_xn else None) + _flat_grads(ctx.spec, dwb, dws)
 
 
+def _is_depthwise(spec: ConvSpec, x, w_basis) -> bool:
+    """Layers the library runs on its direct depthwise kernels (C = 1 per group, O <= 2, <= 9 taps): no G tile, no epilogue accumulation."""
+    return x.shape[1] // spec.groups == 1 and w_basis[0].shape[0] <= 2 and spec.kernel[0] * spec.kernel[1] <= 9
+
+
 class _KanConvPhased(torch.autograd.Function):
     """Conv stage of a basis with trainable per-channel parameters (ReLU-KAN: relu_kan_layers.py:118-136).
     args: spec, x, phases [Cg, 2, n] (phase_low, phase_high per channel), *[w_base_g], *[w_basis_g].
@@ -493,8 +500,16 @@ class _KanConvPhased(torch.autograd.Function):
         dz = dz.contiguous()
         dph = None
         with torch.cuda.device(x.device):
-            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w, phases)
-            if need_p:
+            # ReLU-KAN / Gram: when the input gradient is computed anyway, its launch also accumulates the parameter gradients from the same G tiles
+            # (kan_conv_bwd_data_params); otherwise (first layer of a model, depthwise groups) two more weight-gradient passes deliver them
+            in_epilogue = need_p and need_x and not _is_depthwise(spec, x, w_basis)
+            dpar = None
+            if in_epilogue:                                    # ReLU-KAN: [Cg, 2, n] directly; Gram: 64 slot rows of partial sums
+                dpar = torch.zeros_like(phases) if spec.kind == L.BASIS_RELU else phases.new_zeros((64, spec.n_basis))
+            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w, phases, dparams=dpar)
+            if in_epilogue:
+                dph = dpar if spec.kind == L.BASIS_RELU else dpar.sum(dim=0)
+            if need_p and not in_epilogue:
                 Cg, n = x.shape[1] // G, spec.n_basis
                 W = torch.stack(list(w_basis)).view(G, -1, Cg, n, spec.kernel[0] * spec.kernel[1])
 

@@ -181,6 +181,14 @@ int kan_conv_bwd_data(const float* dz, const float* x, const float* xn, const fl
                       float* dx, float* dxn,
                       const KanGeom* geom, const KanBasis* basis, const float* dz_pm, void* stream);
 
+/* kan_conv_bwd_data that also accumulates the gradient of the basis' trainable device-memory parameters from the same launch.  ReLU-KAN
+ * (relu_kan_layers.py:127-131): dparams[C][2][n_basis] (d phase_low, d phase_high per channel of a group; groups share the table and add up).
+ * GRAM-KAN (gram_kan_layers.py:156-182): dparams[64][n_basis], 64 slot rows of partial sums of d c_k (entries k < 2 stay 0) that the caller
+ * adds up.  The caller zeroes dparams beforehand; every split adds its share with float atomics (scalars; dx stays atomic-free).  Replaces
+ * the runs of the weight-gradient kernel on the parameter-derivative planes (two for ReLU-KAN, n_basis - 2 for GRAM). */
+int kan_conv_bwd_data_params(const float* dz, const float* x, const float* xn, const float* wd, float* dx, float* dxn, float* dparams,
+                             const KanGeom* geom, const KanBasis* basis, const float* dz_pm, void* stream);
+
 /* Gradient w.r.t. the weights in the FLAT packed layout dwp[(tap*C+c)*P + p][o]
  * = sum_pixels expanded[k][pixel] * dz[o][pixel], written as plan.bwd_weight_splits slabs of plan.bwd_weight_slab_elems elements. */
 int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float* dwp,

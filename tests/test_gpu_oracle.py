@@ -379,3 +379,31 @@ def test_constant_plane_spec_vs_oracle(C, O, H, B, G, act, gpu_lib):
     acts = {"silu": nn.SiLU, "gelu": nn.GELU, "none": None}
     layer = K.BesselKANConv2DLayer(C, O, 3, degree=0, padding=1, groups=G, base_activation=acts[act])
     _compare(layer, _cfg("bessel", C, O, groups=G, act=act, degree=0), torch.randn(B, C, H, H), tol_scale=8.0 if H == 2 else 1.0)
+
+
+@pytest.mark.parametrize("fam,G,H", [("relu", 1, 8), ("relu", 2, 4), ("gram", 1, 8), ("gram", 2, 16)], ids=["relu", "relu_g2_4x4", "gram", "gram_g2_16x16"])
+def test_parameter_gradients_from_the_input_gradient_launch_match_the_weight_gradient_route(fam, G, H, gpu_lib):
+    """ReLU-KAN phases / GRAM coefficients: with an input gradient to compute, its launch accumulates them from the same G tiles
+    (kan_conv_bwd_data_params); without one (a model's first layer) the weight-gradient kernel runs on the parameter-derivative planes.
+    Same numbers either way."""
+    torch.manual_seed(3 + H)
+    C, O, B = 6 * G, 16 * G, 5
+    if fam == "relu":
+        layer = K.ReLUKANConv2DLayer(C, O, 3, padding=1, groups=G, base_activation=nn.SiLU).cuda()
+        with torch.no_grad():
+            layer.phase_low.add_(0.05 * torch.randn_like(layer.phase_low)); layer.phase_high.add_(0.05 * torch.randn_like(layer.phase_high))
+        names = ("phase_low", "phase_high")
+    else:
+        layer = K.GRAMKANConv2DLayer(C, O, 3, padding=1, groups=G, degree=4).cuda()
+        with torch.no_grad():
+            layer.beta_weights.normal_(0.0, 0.2)
+        names = ("beta_weights",)
+    x = torch.randn(B, C, H, H, device="cuda")
+    go = torch.randn(B, O, H, H, device="cuda")
+    grads = []
+    for need_x in (True, False):
+        layer.zero_grad(set_to_none=True)
+        layer(x.clone().requires_grad_(need_x)).backward(go)
+        grads.append({n: getattr(layer, n).grad.clone() for n in names})
+    for n in names:
+        assert float(grads[1][n].abs().max()) > 0 and relerr(grads[0][n], grads[1][n]) <= 2e-5, (n, relerr(grads[0][n], grads[1][n]))

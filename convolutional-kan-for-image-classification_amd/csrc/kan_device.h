@@ -163,18 +163,23 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
             }
         }
     } else if (KIND == KAN_BASIS_FOURIER) {
-        // fourier_kan_layers.py:163-187: planes cos(k x), k = 1..G, then sin(k x), k = 1..G (nb = 2G).  The argument is
-        // formed as fl(k * x) exactly as the reference does, so large |x| rounds the same way.
+        // fourier_kan_layers.py:163-187: planes cos(k x), k = 1..G, then sin(k x), k = 1..G (nb = 2G).  ONE sincos(x); the harmonics by the
+        // angle-addition recurrence (c_{k+1}, s_{k+1}) = (c_k c_1 - s_k s_1, s_k c_1 + c_k s_1), restarted at the head of the sine block -- a few ulp
+        // per step against the reference's cos(fl(k x)), whose own argument rounding is of the same size (|k x| ulp); 2G sincosf calls per value
+        // were most of this family's expansion time.
         const int G = bs.nb >> 1;
+        float s1, c1;
+        sincosf(xb, &s1, &c1);
+        float ck = c1, sk = s1, kf = 1.f;
 #pragma unroll
         for (int p = 0; p < KAN_PMAX; ++p) {
             const int j = p - hb;
             if (j >= 0 && j < bs.nb) {
+                if (j == G) { ck = c1; sk = s1; kf = 1.f; }
                 const bool is_cos = j < G;
-                const float k = (float)((is_cos ? j : j - G) + 1);
-                float sn, cs;
-                sincosf(k * xb, &sn, &cs);
-                v[p] = is_cos ? (DERIV ? -k * sn : cs) : (DERIV ? k * cs : sn);
+                v[p] = is_cos ? (DERIV ? -kf * sk : ck) : (DERIV ? kf * ck : sk);
+                const float cn = ck * c1 - sk * s1, sn = sk * c1 + ck * s1;
+                ck = cn; sk = sn; kf += 1.f;
             }
         }
     } else if (KIND == KAN_BASIS_RELU) {

@@ -1,3 +1,4 @@
+# Round profile set (default bench, kernel-trace stats, four PMC passes) under gpurun_out/prof3; summarise with tools/pmc_report.py
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/prof3 && rm -rf $O && mkdir -p $O &&
 python bench.py > $O/bench_default.json 2> $O/bench_default.err &&
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o st -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-aux > $O/stats.log 2>&1 &&

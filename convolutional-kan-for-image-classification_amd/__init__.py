@@ -24,5 +24,5 @@ from .layers.conv_layers import KANConv3DLayer, FastKANConv3DLayer, ChebyKANConv
 from .layers.poly_layers import (BesselKANConv1DLayer, FibonacciKANConv1DLayer, GegenbauerKANConv1DLayer, HermiteKANConv1DLayer,   # noqa: F401,E402
                                  LaguerreKANConv1DLayer, LucasKANConv1DLayer, TaylorKANConv1DLayer, FourierKANConv1DLayer)
 from .layers.wav_layers import (WaveletConvND, WaveletConvNDFast, WaveletConvNDFastPlusOne, WavKANConvNDLayer, WavKANConv2DLayer,   # noqa: F401,E402
-                                WavKANConv1DLayer)
+                                WavKANConv1DLayer, WavKANConv3DLayer)
 from .layers.kan_conv import wavkan_conv   # noqa: F401,E402

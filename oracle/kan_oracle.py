@@ -378,7 +378,7 @@ def wavelet(u: Tensor, kind: str, n_channels: int = 1) -> Tensor:
         aux = torch.where(v <= 1 / 2, torch.ones_like(v), torch.where(v >= 1, torch.zeros_like(v), torch.cos(math.pi / 2 * nu(2 * v - 1))))
         return torch.sin(math.pi * v) * aux
     if kind == "shannon":                              # the Hamming window runs over the CHANNEL axis (x.size(2), wav_kan_layers.py:180-186)
-        window = torch.hamming_window(u.size(2), periodic=False, dtype=u.dtype, device=u.device).view(1, 1, -1, 1, 1)
+        window = torch.hamming_window(u.size(2), periodic=False, dtype=u.dtype, device=u.device).view(1, 1, -1, *([1] * (u.dim() - 3)))
         return torch.sinc(u / math.pi) * window
     raise ValueError(kind)
 
@@ -388,13 +388,14 @@ def wavkan_conv2d(x: Tensor, w_base: Sequence[Tensor], scale: Sequence[Tensor], 
                   norm: Optional[Sequence[Callable[[Tensor], Tensor]]] = None, pre_norm_out: Optional[list] = None) -> Tensor:
     """norm(wavelet_out(sum_c conv(psi((x_c - t_oc) / s_oc), Wk[o, c])) + conv(SiLU(x), W_b))  (wav_kan_layers.py:430-443; the three
     wavelet-conv versions, :186-217 / :257-276 / :318-338, are this sum over differently shaped weights).  scale / translation: per group
-    [1, O, C, 1, 1]; w_wavelet: per group [O, C, kh, kw]; w_out: per group [O, O, 1, 1]."""
+    [1, O, C, 1, 1]; w_wavelet: per group [O, C, kh, kw]; w_out: per group [O, O, 1, 1] -- or their 3-D counterparts ([B, C, D, H, W] input,
+    one more unit / kernel axis: WavKANConv3DLayer, :457-464)."""
     def one(xg, g):
         base = _conv(F.silu(xg), w_base[g], stride, padding, dilation)
         psi = wavelet((xg.unsqueeze(1) - translation[g]) / scale[g], wavelet_type)           # [B, O, C, H, W]
         O = psi.shape[1]
         u = torch.cat([_conv(psi[:, o], w_wavelet[g][o:o + 1], stride, padding, dilation) for o in range(O)], dim=1)
-        z = F.conv2d(u, w_out[g]) + base
+        z = _conv(u, w_out[g], 1, 0, 1) + base                # the 1x1(x1) `wavelet_out` conv
         if pre_norm_out is not None:
             pre_norm_out.append(z)
         return F.instance_norm(z, eps=1e-5) if norm is None else norm[g](z)

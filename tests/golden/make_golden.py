@@ -226,6 +226,8 @@ WAV_CASES = [
     C("wav", "1d_morlet_s2", 2, 4, 6, 1, 33, ndim=1, s=2, extra={"wavelet_type": "morlet", "wav_version": "fast"}),
     C("wav", "1d_mexican_plus1_g2", 2, 4, 6, 1, 21, ndim=1, groups=2, extra={"wavelet_type": "mexican_hat", "wav_version": "fast_plus_one"}),
     C("wav", "small_planes", 8, 24, 40, 4, 4, extra={"wavelet_type": "mexican_hat", "wav_version": "fast"}),
+    C("wav", "3d_tiny", 2, 3, 4, 6, 6, ndim=3, D=5, extra={"wavelet_type": "mexican_hat", "wav_version": "fast"}),
+    C("wav", "3d_dog_base_s2g2_p2", 2, 4, 6, 7, 6, ndim=3, D=6, s=2, p=2, groups=2, extra={"wavelet_type": "dog", "wav_version": "base"}, norm_kwargs={"affine": True}),
 ]
 
 
@@ -240,8 +242,9 @@ def build_ref(c):
     if c["kind"] == "wav":
         kw.update(c.get("norm_kwargs", {}))
         kw.update(c.get("extra", {}))
-        kw["norm_layer"] = (nn.BatchNorm1d if one_d else NORMS[c["norm"]]) if "norm" in c else (nn.InstanceNorm1d if one_d else nn.InstanceNorm2d)
-        return (REF_LAYERS.WavKANConv1DLayer if one_d else REF_LAYERS.WavKANConv2DLayer)(c["C"], c["O"], **kw)
+        nd = c.get("ndim", 2)
+        kw["norm_layer"] = (nn.BatchNorm1d if one_d else NORMS[c["norm"]]) if "norm" in c else {1: nn.InstanceNorm1d, 2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}[nd]
+        return {1: REF_LAYERS.WavKANConv1DLayer, 2: REF_LAYERS.WavKANConv2DLayer, 3: REF_LAYERS.WavKANConv3DLayer}[nd](c["C"], c["O"], **kw)
     if c["kind"] == "relu":
         kw.update(c.get("norm_kwargs", {}))
         kw.update(c.get("extra", {}))

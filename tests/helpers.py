@@ -34,7 +34,7 @@ def layer_kwargs(c):
     if c["kind"] == "wav":
         one_d = c.get("ndim", 2) == 1
         kw.update(c.get("extra", {}))
-        kw["norm_layer"] = (nn.BatchNorm1d if one_d else NORMS[c["norm"]]) if "norm" in c else (nn.InstanceNorm1d if one_d else nn.InstanceNorm2d)
+        kw["norm_layer"] = (nn.BatchNorm1d if one_d else NORMS[c["norm"]]) if "norm" in c else {1: nn.InstanceNorm1d, 2: nn.InstanceNorm2d, 3: nn.InstanceNorm3d}[c.get("ndim", 2)]
         return kw
     if c["kind"] == "gram":
         kw["degree"] = c["degree"]
@@ -63,7 +63,7 @@ def layer_kwargs(c):
 def build_layer(c):
     import convkan_amd as K
     if c["kind"] == "wav":
-        return (K.WavKANConv1DLayer if c.get("ndim", 2) == 1 else K.WavKANConv2DLayer)(c["C"], c["O"], **layer_kwargs(c))
+        return {1: K.WavKANConv1DLayer, 2: K.WavKANConv2DLayer, 3: K.WavKANConv3DLayer}[c.get("ndim", 2)](c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] == "gram":
         return K.GRAMKANConv2DLayer(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] == "relu":

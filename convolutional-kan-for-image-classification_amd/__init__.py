@@ -26,3 +26,5 @@ from .layers.poly_layers import (BesselKANConv1DLayer, FibonacciKANConv1DLayer, 
 from .layers.wav_layers import (WaveletConvND, WaveletConvNDFast, WaveletConvNDFastPlusOne, WavKANConvNDLayer, WavKANConv2DLayer,   # noqa: F401,E402
                                 WavKANConv1DLayer, WavKANConv3DLayer)
 from .layers.kan_conv import wavkan_conv   # noqa: F401,E402
+from .layers.poly_layers import (BesselKANConv3DLayer, FibonacciKANConv3DLayer, GegenbauerKANConv3DLayer, HermiteKANConv3DLayer,   # noqa: F401,E402
+                                 LaguerreKANConv3DLayer, LucasKANConv3DLayer, TaylorKANConv3DLayer, FourierKANConv3DLayer)

@@ -29,7 +29,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
-from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm)
+from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm, _norm3d, conv3d_stage)
 from .conv_layers import _need_conv2d as _need_conv1d_or_2d
 
 
@@ -55,7 +55,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
 
     def _setup(self, conv_class, norm_class, input_dim, output_dim, kernel_size, degree, groups, padding, stride, dilation, ndim,
                base_activation, dropout, norm_kwargs, none_is_identity=True):
-        _need_conv1d_or_2d(conv_class, ndim)          # 1-D layers run the 2-D kernels on [B, C, 1, L] (_HipLayer)
+        _need_conv1d_or_2d(conv_class, ndim, allow_3d=True)      # 1-D layers run the 2-D kernels on [B, C, 1, L] (_HipLayer); 3-D: conv3d_stage
         _check_groups(groups, input_dim, output_dim)
         if degree < self._min_degree:
             raise ValueError(self._min_degree_msg)
@@ -91,8 +91,22 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
         n = self._n_planes()
         return self._spec(kind=L.BASIS_POLY, n_basis=n, order=1, act=self._act_code, p0=0.0, p1=0.0, table=_table(self._coeffs(), n))
 
+    def _forward3d(self, x):
+        """[B, C, D, H, W] layers (the ...KANConv3DLayer shims of the reference): each depth tap is one launch set of the 2-D kernels (conv3d_stage)."""
+        n = self.degree + 1
+        kw = dict(kind=L.BASIS_POLY, n_basis=n, order=1, act=self._act_code, p0=0.0, p1=0.0, table=_table(self._coeffs(), n))
+        xa, xb = self._base_input(x)
+        z = conv3d_stage(kw, self.kernel_size, self.stride, self.padding, self.dilation, self.groups, xa, xb,
+                         [m.weight for m in self.base_conv], [m.weight for m in self.poly_conv])
+        y = _norm3d(self.layer_norm, self.prelus, z, self.output_dim_group)
+        return self.dropout(y) if self.dropout is not None else y
+
     def forward(self, x, pool: bool = False):
         """`pool=True`: max_pool2d(layer(x), 2, 2) with the pooling inside the InstanceNorm+PReLU kernels (see KANConvNDLayer)."""
+        if self.ndim == 3:
+            if pool:
+                raise NotImplementedError("pool=True is a 2-D fusion")
+            return self._forward3d(x)
         spec = self.conv_spec()
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.poly_conv)
@@ -144,6 +158,16 @@ class BesselKANConv1DLayer(BesselKANConvNDLayer):
                          ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class BesselKANConv3DLayer(BesselKANConvNDLayer):
+    """The 3-D shim (bessel_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Fibonacci
 class FibonacciKANConvNDLayer(_RecurrenceKANConvNDLayer):
     """F_0 = 0, F_1 = 1, F_n = t F_{n-1} + F_{n-2}  (fibonacci_kan_layers.py compute_fibonacci_basis)."""
@@ -176,6 +200,16 @@ class FibonacciKANConv1DLayer(FibonacciKANConvNDLayer):
         super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class FibonacciKANConv3DLayer(FibonacciKANConvNDLayer):
+    """The 3-D shim (fibonacci_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Gegenbauer
@@ -214,6 +248,16 @@ class GegenbauerKANConv1DLayer(GegenbauerKANConvNDLayer):
                          dilation=dilation, ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class GegenbauerKANConv3DLayer(GegenbauerKANConvNDLayer):
+    """The 3-D shim (gegenbauer_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, alpha_param, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, alpha_param=alpha_param, groups=groups, padding=padding, stride=stride,
+                         dilation=dilation, ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Hermite
 class HermiteKANConvNDLayer(_RecurrenceKANConvNDLayer):
     """H_0 = 1, H_1 = 2t, H_n = 2t H_{n-1} - 2(n-1) H_{n-2}  (hermite_kan_layers.py:117-146; base_activation is called as given, :65)."""
@@ -244,6 +288,16 @@ class HermiteKANConv1DLayer(HermiteKANConvNDLayer):
         super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class HermiteKANConv3DLayer(HermiteKANConvNDLayer):
+    """The 3-D shim (hermite_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Laguerre
@@ -282,6 +336,16 @@ class LaguerreKANConv1DLayer(LaguerreKANConvNDLayer):
                          dilation=dilation, ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class LaguerreKANConv3DLayer(LaguerreKANConvNDLayer):
+    """The 3-D shim (laguerre_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, alpha, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, alpha=alpha, groups=groups, padding=padding, stride=stride,
+                         dilation=dilation, ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Lucas
 class LucasKANConvNDLayer(_RecurrenceKANConvNDLayer):
     """L_0 = 2, L_1 = t, L_n = t L_{n-1} + L_{n-2}  (lucas_kan_layers.py:140-174)."""
@@ -312,6 +376,16 @@ class LucasKANConv1DLayer(LucasKANConvNDLayer):
         super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class LucasKANConv3DLayer(LucasKANConvNDLayer):
+    """The 3-D shim (lucas_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Taylor
@@ -351,6 +425,16 @@ class TaylorKANConv1DLayer(TaylorKANConvNDLayer):
                          ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
+class TaylorKANConv3DLayer(TaylorKANConvNDLayer):
+    """The 3-D shim (taylor_kan_layers.py, ...KANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, degree, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, degree=degree, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
 # ------------------------------------------------------------------------------------------- Fourier
 class FourierKANConvNDLayer(_HipLayer):
     """fourier_kan_layers.py:63-212: y = Dropout(PReLU(norm(conv(act(x), W_base) + conv([cos(kx)]_k ++ [sin(kx)]_k, W_fourier)))),
@@ -359,7 +443,7 @@ class FourierKANConvNDLayer(_HipLayer):
     def __init__(self, conv_class, norm_class, input_dim, output_dim, kernel_size, grid_size, groups=1, padding=0, stride=1, dilation=1,
                  ndim: int = 2, base_activation=nn.GELU, dropout: float = 0.0, smooth_initialization: bool = False, **norm_kwargs):
         super().__init__()
-        _need_conv1d_or_2d(conv_class, ndim)
+        _need_conv1d_or_2d(conv_class, ndim, allow_3d=True)
         _check_groups(groups, input_dim, output_dim)
         if grid_size < 1:
             raise ValueError('grid_size must be at least 1')
@@ -388,7 +472,17 @@ class FourierKANConvNDLayer(_HipLayer):
     def conv_spec(self) -> ops.ConvSpec:
         return self._spec(kind=L.BASIS_FOURIER, n_basis=2 * self.grid_size, order=0, act=self._act_code, p0=0.0, p1=0.0, table=())
 
+    def _forward3d(self, x):
+        kw = dict(kind=L.BASIS_FOURIER, n_basis=2 * self.grid_size, order=0, act=self._act_code, p0=0.0, p1=0.0, table=())
+        xa, xb = self._base_input(x)
+        z = conv3d_stage(kw, self.kernel_size, self.stride, self.padding, self.dilation, self.groups, xa, xb,
+                         [m.weight for m in self.base_conv], [m.weight for m in self.fourier_conv])
+        y = _norm3d(self.layer_norm, self.prelus, z, self.output_dim_group)
+        return self.dropout(y) if self.dropout is not None else y
+
     def forward(self, x):
+        if self.ndim == 3:
+            return self._forward3d(x)
         spec = self.conv_spec()
         x = self._lift(x)
         wb, ws = self._w(self.base_conv), self._w(self.fourier_conv)
@@ -420,6 +514,16 @@ class FourierKANConv1DLayer(FourierKANConvNDLayer):
         super().__init__(conv_class=nn.Conv1d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
                          kernel_size=kernel_size, grid_size=grid_size, groups=groups, padding=padding, stride=stride, dilation=dilation,
                          ndim=1, base_activation=base_activation, dropout=dropout, **norm_kwargs)
+
+
+class FourierKANConv3DLayer(FourierKANConvNDLayer):
+    """The 3-D shim (fourier_kan_layers.py, FourierKANConv3DLayer): [B, C, D, H, W], nn.Conv3d weights, InstanceNorm3d; depth taps around the 2-D kernels."""
+
+    def __init__(self, input_dim, output_dim, kernel_size, grid_size, groups=1, padding=0, stride=1, dilation=1,
+                 base_activation=nn.GELU, dropout=0.0, norm_layer=nn.InstanceNorm3d, **norm_kwargs):
+        super().__init__(conv_class=nn.Conv3d, norm_class=norm_layer, input_dim=input_dim, output_dim=output_dim,
+                         kernel_size=kernel_size, grid_size=grid_size, groups=groups, padding=padding, stride=stride, dilation=dilation,
+                         ndim=3, base_activation=base_activation, dropout=dropout, **norm_kwargs)
 
 
 # ------------------------------------------------------------------------------------------- Jacobi

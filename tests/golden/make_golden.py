@@ -174,6 +174,10 @@ CASES_3D = [
     C("rbf", "3d_s2g2_p0", 2, 4, 6, 7, 6, ndim=3, D=6, s=2, groups=2, p=0, xs=2.0),
     C("cheby", "3d_tiny", 2, 3, 4, 6, 6, ndim=3, D=5),
     C("cheby", "3d_deg4_d2_affine", 2, 4, 6, 7, 7, ndim=3, D=6, degree=4, d=2, p=2, groups=2, norm_kwargs={"affine": True}),
+    # 3-D shims of the recurrence families and FourierKAN (<family>_kan_layers.py: the ...KANConv3DLayer classes)
+    C("lucas", "3d_deg3_g2", 2, 4, 6, 6, 6, ndim=3, D=5, degree=3, groups=2, act="silu"),
+    C("gegenbauer", "3d_deg4_s2_affine", 2, 3, 5, 7, 6, ndim=3, D=6, degree=4, s=2, extra={"alpha_param": 1.5}, norm_kwargs={"affine": True}),
+    C("fourier", "3d_g3_d2p0", 2, 3, 4, 7, 7, ndim=3, D=7, degree=3, d=2, p=0, xs=2.0),
 ]
 
 
@@ -260,11 +264,13 @@ def build_ref(c):
             kw["norm_layer"] = NORMS[c["norm"]]
         if "act" in c:
             kw["base_activation"] = ACTS[c["act"]]
+        three_d = c.get("ndim", 2) == 3
         if c["kind"] == "fourier":
-            return (REF_LAYERS.FourierKANConv1DLayer if one_d else REF_LAYERS.FourierKANConv2DLayer)(c["C"], c["O"], grid_size=c["degree"], **kw)
+            cls = REF_LAYERS.FourierKANConv3DLayer if three_d else REF_LAYERS.FourierKANConv1DLayer if one_d else REF_LAYERS.FourierKANConv2DLayer
+            return cls(c["C"], c["O"], grid_size=c["degree"], **kw)
         if c["kind"] == "legendre":
             kw.pop("base_activation", None)
-        name = POLY_FAMILIES[c["kind"]].replace("2D", "1D") if one_d else POLY_FAMILIES[c["kind"]]
+        name = POLY_FAMILIES[c["kind"]].replace("2D", "3D" if three_d else "1D") if (one_d or three_d) else POLY_FAMILIES[c["kind"]]
         return getattr(REF_LAYERS, name)(c["C"], c["O"], degree=c["degree"], **kw)
     kw.update(c.get("norm_kwargs", {}))
     if "norm" in c:

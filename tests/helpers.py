@@ -69,7 +69,8 @@ def build_layer(c):
     if c["kind"] == "relu":
         return (K.ReLUKANConv1DLayer if c.get("ndim", 2) == 1 else K.ReLUKANConv2DLayer)(c["C"], c["O"], **layer_kwargs(c))
     if c["kind"] in POLY:
-        name = POLY[c["kind"]].replace("2D", "1D") if c.get("ndim", 2) == 1 else POLY[c["kind"]]
+        nd = c.get("ndim", 2)
+        name = POLY[c["kind"]].replace("2D", f"{nd}D") if nd != 2 else POLY[c["kind"]]
         return getattr(K, name)(c["C"], c["O"], **layer_kwargs(c))
     if c.get("ndim", 2) == 3:
         return {"bspline": K.KANConv3DLayer, "rbf": K.FastKANConv3DLayer, "cheby": K.ChebyKANConv3DLayer}[c["kind"]](

@@ -19,12 +19,23 @@ import time
 # dmabuf IPC is the only mode the host driver supports: must be in the environment before the first HIP call of any rank
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import torch
-import torch.distributed as dist
-import torch.nn.functional as F
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# torch (whose import maps libamdhip64 / libhsa-runtime64 into the process) is loaded by the WORKERS only: the launcher parent of
+# `--gpus N` decides from its arguments, counts GPUs in sysfs and starts its ranks without ever loading the HIP runtime -- on an 8-rank
+# node there is no 9th process holding the devices open (tests/test_bench_launcher.py checks /proc/self/maps at Popen time).
+torch = dist = F = None
+
+
+def _load_torch():
+    global torch, dist, F
+    if torch is None:
+        import torch as _torch
+        import torch.distributed as _dist
+        import torch.nn.functional as _F
+        torch, dist, F = _torch, _dist, _F
+    return torch
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, exact fp32
 GFLOP_PER_IMAGE = 8.249            # dense algorithmic count fwd+bwd for KAN-VGG11 @32x32
@@ -46,6 +57,7 @@ WORKLOADS = {
 
 
 def build_model(device, workload="kan_vgg11"):
+    _load_torch()
     torch.manual_seed(0)
     if workload == "kan_vgg11":
         from convkan_amd.models import vggkan
@@ -74,10 +86,30 @@ def one_step(model, x, t, reducer=None):
     return loss
 
 
+def traced_step(model, x, t, reducer):
+    """One untimed step under reducer.trace_step: offsets (ms from the start of backward, this rank's HIP events) of every bucket's
+    "last gradient written", collective start and end, the end of backward on the compute stream, and `exposed_ms` -- how long
+    the compute stream then sits in finish() waiting for collectives (0 = the exchange hid completely under backward)."""
+    out = {}
+    try:
+        model.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(model(x), t)
+        with reducer.trace_step(out):
+            out["t0"] = torch.cuda.Event(enable_timing=True)
+            out["t0"].record(torch.cuda.current_stream())
+            loss.backward()
+            reducer.finish()
+        out.pop("t0", None)
+    except Exception as e:                                # diagnostics only
+        out = {"trace_error": f"{type(e).__name__}: {e}"[:200]}
+    return out
+
+
 def train_step_timing(model, x, t, steps, warmup):
     """Auxiliary figure, N = 1 only: the same step followed by the fused AdamW update (generic_train.py:24: lr 1e-3,
     weight_decay 1e-4).  `value` above stays the fwd+bwd metric of BASELINE.json / SURVEY.md 8(d); this shows what a
     full training step costs.  Runs after the main measurement (it moves the parameters into the optimizer's flat block)."""
+    _load_torch()
     try:
         from convkan_amd import FusedAdamW
         opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
@@ -144,6 +176,7 @@ def cpu_baseline(batch: int, iters: int, warmup: int):
     """the oracle (CPU restatement of the reference op sequence kan_layers.py:197-247, torch CPU ops) on
     this box's host cores -- batch 256, >= 3 warm-up + >= 10 timed iterations at every core this process may use, plus one short
     run pinned to 8 threads for comparison with the build container's indicative 28-33 img/s."""
+    _load_torch()
     from oracle.kan_oracle import OracleKANVGG
     torch.manual_seed(0)
     m = OracleKANVGG().train()
@@ -213,6 +246,7 @@ def summarise(prof, elapsed_s, steps, batch, world, gflop_per_image):
 
 
 def timed_steps(model, x, t, steps, warmup, reducer=None, barrier=None):
+    _load_torch()
     from convkan_amd import ops
     barrier = barrier or torch.cuda.synchronize
     for _ in range(warmup):
@@ -250,18 +284,38 @@ def other_workload(name, device, steps, warmup):
 
 
 # --------------------------------------------------------------------------------------------------- multi-rank launch
-def launch_ranks(n: int, argv, script: str = None, check_devices: bool = True):
+def kfd_gpu_count():
+    """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs; CPUs have simd_count 0), cut to the
+    *_VISIBLE_DEVICES selection if one is set.  Pure sysfs: no HIP / HSA call, so the caller's process never opens a device.
+    None when the topology is not readable (then the ranks themselves fail loudly if a device is missing)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):            # no amdgpu compute driver on this machine at all
+        return 0
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        sel = os.environ.get(var)
+        if sel is not None:
+            n = min(n, len([v for v in sel.split(",") if v.strip() != ""]))
+    return n
+
+
+def launch_ranks(n: int, argv, script: str = None, check_devices: bool = True, pre_popen=None):
     """`python bench.py --gpus N` with N > 1 (or --spawn): start N fresh worker processes -- one per GPU, a
-    torch.distributed.run child -- relay rank 0's JSON line and exit with the child's code.  This parent never touches the GPU
-    (no HIP call, nothing re-executed): it decides from the arguments alone, before anything else runs."""
-    have = None
-    if check_devices:
-        try:
-            have = torch.cuda.device_count()          # device enumeration only; does not create a HIP context
-        except Exception:
-            pass
+    torch.distributed.run child -- relay rank 0's JSON line and exit with the child's code.  This parent never touches the GPU:
+    it has not imported torch (no HIP / HSA library is even mapped), counts devices in sysfs (kfd_gpu_count) and re-executes nothing;
+    it decides from the arguments alone, before anything else runs."""
+    have = kfd_gpu_count() if check_devices else None
     if have is not None and have < n:
         raise SystemExit(f"bench.py --gpus {n}: this node exposes {have} GPU(s)")
+    if pre_popen is not None:                          # test hook: inspect the parent just before it starts the ranks
+        pre_popen()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -303,6 +357,7 @@ def main():
     world_env = os.environ.get("WORLD_SIZE")
     if (args.gpus > 1 or args.spawn) and world_env is None:
         launch_ranks(args.gpus, sys.argv[1:])           # does not return
+    _load_torch()                                       # workers (and the plain single-GPU run) only
     # stdout carries exactly ONE line (the JSON).  Native libraries print banners there (RCCL: "RCCL version : ..." at
     # communicator creation), so fd 1 points at stderr until the result is ready.
     sys.stdout.flush()
@@ -350,10 +405,16 @@ def main():
     elapsed, prof, loss = timed_steps(model, x, t, args.steps, args.warmup, reducer, barrier)
     if rank == 0:
         print(f"[bench] {args.steps} steps in {elapsed:.3f}s on {world} GPU(s)", file=sys.stderr, flush=True)
+    per_rank, trace = [elapsed], {}
     if use_dist:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)                       # each rank's own clock over the same K steps (spread = load imbalance / stragglers)
+        per_rank = [float(v.item()) for v in every]
+        elapsed = max(per_rank)                          # the contract's MAX over ranks
+        # one more, UNTIMED step with HIP events around every bucket's collective: where the all-reduce sits relative to backward
+        trace = traced_step(model, x, t, reducer)
+        barrier()
 
     if rank == 0:
         ips, roof = summarise(prof, elapsed, args.steps, args.batch, world, wl["gflop_per_image"])
@@ -374,6 +435,9 @@ def main():
         if reducer is not None:
             out["allreduce"] = {"buckets": len(reducer.buckets), "bucket_mb": args.bucket_mb,
                                 "bytes_per_step": sum(b.flat.numel() * 4 for b in reducer.buckets), "op": "avg, side stream, reverse order"}
+            out["allreduce"].update(trace)               # exposed_ms, backward_end_ms, per-bucket ready / start / end offsets (rank 0, one untimed step)
+            out["ms_per_step_ranks"] = {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3),
+                                        "all": [round(v / args.steps * 1e3, 3) for v in per_rank]}
         aux = world == 1 and not use_dist and args.workload == "kan_vgg11" and not args.no_aux
         if aux:
             out["with_optimizer"] = train_step_timing(model, x, t, args.steps, max(3, args.warmup // 2))

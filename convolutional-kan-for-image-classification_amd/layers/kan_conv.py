@@ -5,7 +5,8 @@ reference's models use (models/kan_vgg.py:73-101, models/kan_alexnet.py:54-69). 
 basis families of the hot path, the eight three-term-recurrence polynomial families of SURVEY.md
 section 8(f) rank 3 (Bessel, Fibonacci, Gegenbauer, Hermite, Jacobi, Laguerre, Lucas, Taylor), FourierKAN and the
 plain ``conv`` helper, plus LegendreKAN, BersnsteinKAN, ReLU-KAN and GRAM-KAN (trainable parameters inside the basis:
-device-side phase / coefficient tables) -- 17 of the reference's 18 keys.  Not built: Wav-KAN.
+device-side phase / coefficient tables) and Wav-KAN (per-(output, input) wavelets on the direct kernels of csrc/wavkan.inc) --
+all 18 of the reference's keys.
 """
 from typing import Callable, List, Optional, Tuple, Union
 

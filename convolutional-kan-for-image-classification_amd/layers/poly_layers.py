@@ -93,7 +93,7 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
 
     def _forward3d(self, x):
         """[B, C, D, H, W] layers (the ...KANConv3DLayer shims of the reference): each depth tap is one launch set of the 2-D kernels (conv3d_stage)."""
-        n = self.degree + 1
+        n = self._n_planes()                                     # (Taylor: degree planes, not degree + 1 -- same source as conv_spec())
         kw = dict(kind=L.BASIS_POLY, n_basis=n, order=1, act=self._act_code, p0=0.0, p1=0.0, table=_table(self._coeffs(), n))
         xa, xb = self._base_input(x)
         z = conv3d_stage(kw, self.kernel_size, self.stride, self.padding, self.dilation, self.groups, xa, xb,

@@ -206,9 +206,13 @@ def _stack(ws: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
 #     ~20 us for an 85 MB layer) and the pack kernels return at once when the fingerprint equals the previous call's.  This is
 #     what catches writes the version counter cannot see -- `p.data.mul_()`, `dist.broadcast(p.data)`, EMA idioms, any
 #     raw-pointer writer.  KAN_PACK_SAMPLE=n (> 1) fingerprints every n-th group of four elements instead of all of them.
-# KAN_PACK_CACHE=0 disables the cache (pack on every call); otherwise it is the number of (layer, geometry) entries kept (LRU).
+# KAN_PACK_CACHE=0 disables the cache (pack on every call); otherwise it is the number of (layer, packed layout) entries kept (LRU),
+# bounded in bytes as well by KAN_PACK_CACHE_BYTES (default 16 GiB of the 288 GB).  An entry is keyed by what FIXES the packed layouts
+# (channels, outputs, planes, kernel, step shape, halo pair order) -- not by batch size or resolution, so a last partial batch, another
+# evaluation batch size or variable-size inputs share one copy of each layer's layouts instead of adding ~0.66 GB per shape for KAN-VGG11.
 _PACKED: "OrderedDict[tuple, PackedWeights]" = OrderedDict()
 _PACK_CACHE_MAX = int(os.environ.get("KAN_PACK_CACHE", "256"))
+_PACK_CACHE_BYTES = int(os.environ.get("KAN_PACK_CACHE_BYTES", str(16 << 30)))
 _PACK_SAMPLE = max(1, int(os.environ.get("KAN_PACK_SAMPLE", "1")))
 PACK_STATS = {"calls": 0, "forced": 0}               # host-side counters (tests, tools)
 
@@ -219,6 +223,15 @@ class PackedWeights:
     def __init__(self):
         self.wp = self.wd = self.ring = None
         self.cur, self.stamps = 0, None
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in (self.wp, self.wd) if t is not None)
+
+
+def _layout_key(spec: "ConvSpec", geom, plan) -> tuple:
+    """What the packed layouts wp / wd depend on (kanconv.hip: wp_row, k_pack_bwd_data): the per-group channel / output counts, the
+    step shape (IPC, KC), the padded dims, and whether the forward uses the halo kernels' pair order.  B, H, W enter only through those."""
+    return (spec, geom.C, geom.O, plan.P, plan.IPC, plan.KC, plan.Kpad, plan.Opad, plan.fwd_halo, plan.packed_weight_bytes, plan.bwd_data_weight_bytes)
 
 
 @lru_cache(maxsize=512)
@@ -239,7 +252,7 @@ def _packed_entry(key, owners):
         _PACKED[key] = ent
         for o in owners:                              # drop the layouts when a weight tensor dies
             weakref.finalize(o, _PACKED.pop, key, None)
-        while len(_PACKED) > _PACK_CACHE_MAX:
+        while len(_PACKED) > _PACK_CACHE_MAX or (len(_PACKED) > 1 and sum(e.nbytes() for e in _PACKED.values()) > _PACK_CACHE_BYTES):
             _PACKED.popitem(last=False)
     else:
         _PACKED.move_to_end(key)
@@ -260,7 +273,9 @@ def _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, p
     if (ws.data_ptr() | (wb.data_ptr() if wb is not None else 0)) & 15:
         return fresh()
     owners = [_owner(w) for w in (wb, ws) if w is not None]
-    ent = _packed_entry((plan_key, device.index) + tuple(id(o) for o in owners), owners)
+    if not all(o.is_leaf for o in owners):            # a per-call temporary of the autograd graph (weight slices made contiguous, re-ordered
+        return fresh()                                # plane-major weights): an entry would be built and dropped on every call
+    ent = _packed_entry((_layout_key(spec, geom, plan), device.index) + tuple(id(o) for o in owners), owners)
     stamps = [(w.data_ptr(), o._version, tuple(w.shape)) for w, o in zip((w for w in (wb, ws) if w is not None), owners)]
     force = ent.wp is None or ent.stamps != stamps or (need_dgrad and ent.wd is None)
     if ent.wp is None:
@@ -730,7 +745,8 @@ def _image_runs(spec: ConvSpec, x: torch.Tensor, out_channels: int) -> Optional[
         return None
     if per_image > MAX_TENSOR_BYTES:
         raise L.KanConvError(f"one image's activations ({per_image} bytes) exceed the {MAX_TENSOR_BYTES}-byte launch limit")
-    runs = -(-B * per_image // MAX_TENSOR_BYTES)
+    fit = MAX_TENSOR_BYTES // per_image               # images one launch can take; equal-ish runs of at most that many
+    runs = -(-B // fit)
     return -(-B // runs)
 
 

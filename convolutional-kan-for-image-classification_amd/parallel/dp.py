@@ -71,6 +71,7 @@ class BucketedGradReducer:
         self.avg_in_collective = bool(dist.is_initialized() and dist.get_backend(group) == "nccl")
         self.side = torch.cuda.Stream(device=plist[0].device) if self.cuda else None
         self._armed = True
+        self._trace = None                          # see trace_step()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in plist]
         # conv-KAN weights: let the weight-gradient kernels write into the bucket directly (ops.GRAD_SINKS); the hook then
         # finds .grad already in place and skips its copy
@@ -113,15 +114,53 @@ class BucketedGradReducer:
         if self.world == 1 and not self.always_reduce:
             return
         if self.cuda:
-            self.side.wait_stream(torch.cuda.current_stream(b.flat.device))
+            tr = self._trace
+            cur = torch.cuda.current_stream(b.flat.device)
+            if tr is not None:                      # when the bucket's last gradient is on the compute stream
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record(cur)
+            self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
+                if tr is not None:
+                    ev[1].record(self.side)
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM,
                                          group=self.group, async_op=True)
+                if tr is not None:                  # the backend runs collectives on a stream of its own: make the (otherwise idle) side
+                    b.work.wait()                   # stream wait for this one, so that an event on it marks the collective's end
+                    ev[2].record(self.side)
+                    tr["buckets"].append((self.buckets.index(b), ev))
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def finish(self):
         """Flush buckets whose gradients never all arrived (unused parameters), wait, scale, publish as p.grad."""
+        tr = self._trace if self.cuda else None
+        if tr is not None:                          # the compute stream has every backward kernel enqueued: "backward ends" here
+            tr["fin0"] = torch.cuda.Event(enable_timing=True); tr["fin0"].record(torch.cuda.current_stream(self.buckets[0].flat.device))
+        self._finish()
+        if tr is not None:
+            tr["fin1"] = torch.cuda.Event(enable_timing=True); tr["fin1"].record(torch.cuda.current_stream(self.buckets[0].flat.device))
+
+    @contextlib.contextmanager
+    def trace_step(self, out: dict):
+        """Diagnostics for ONE step (outside any timed region): HIP events around every bucket's collective and around finish().
+        On exit (after a device sync) `out` holds, in ms relative to the event `out['t0']` the caller recorded before backward:
+          exposed_ms          time the compute stream spends blocked in finish() after its last backward kernel (the un-overlapped tail),
+          buckets[i]          {ready_ms: last gradient of the bucket written, start_ms / end_ms: its all-reduce on the side stream, mb}."""
+        self._trace = {"buckets": []}
+        try:
+            yield self
+        finally:
+            tr, self._trace = self._trace, None
+            if self.cuda and "fin1" in tr and out.get("t0") is not None:
+                torch.cuda.synchronize()
+                t0 = out.pop("t0")
+                out["backward_end_ms"] = round(t0.elapsed_time(tr["fin0"]), 3)
+                out["exposed_ms"] = round(tr["fin0"].elapsed_time(tr["fin1"]), 3)
+                out["buckets"] = [{"bucket": i, "mb": round(self.buckets[i].flat.numel() * 4 / 2 ** 20, 1), "ready_ms": round(t0.elapsed_time(e[0]), 3),
+                                   "start_ms": round(t0.elapsed_time(e[1]), 3), "end_ms": round(t0.elapsed_time(e[2]), 3)} for i, e in tr["buckets"]]
+
+    def _finish(self):
         for b in self.buckets:
             if b.pending != 0:                      # some parameter had no gradient this step: send what we have
                 for v, p in zip(b.views, b.params):

@@ -178,6 +178,9 @@ CASES_3D = [
     C("lucas", "3d_deg3_g2", 2, 4, 6, 6, 6, ndim=3, D=5, degree=3, groups=2, act="silu"),
     C("gegenbauer", "3d_deg4_s2_affine", 2, 3, 5, 7, 6, ndim=3, D=6, degree=4, s=2, extra={"alpha_param": 1.5}, norm_kwargs={"affine": True}),
     C("fourier", "3d_g3_d2p0", 2, 3, 4, 7, 7, ndim=3, D=7, degree=3, d=2, p=0, xs=2.0),
+    # Taylor holds `degree` planes, not degree + 1 (taylor_kan_layers.py:107-117): the 3-D shim must size its basis from the same count
+    C("taylor", "3d_deg3_s2", 2, 3, 4, 6, 6, ndim=3, D=5, degree=3, s=2, act="silu"),
+    C("taylor", "3d_deg1_g2", 2, 4, 6, 5, 5, ndim=3, D=4, degree=1, groups=2),
 ]
 
 

@@ -155,3 +155,63 @@ def _oracle_forward_2d(c, layer, sd, norms, geo, x, pre):
                                 act=ACT_FN[c.get("act", "gelu")], norm=norms, pre_norm_out=pre, **c.get("extra", {}), **geo)
     return O.chebykan_conv2d(x, [sd[f"poly_conv.{g}.weight"] for g in range(G)], degree=layer.degree, norm=norms,
                              pre_norm_out=pre, **geo)
+
+
+# ------------------------------------------------------------------------------------------ the calibrated tolerance rule
+def oracle_run(cfg, layer, x, go, dtype):
+    """The CPU oracle with `layer`'s parameters in `dtype` (fp64 = the yardstick, fp32 = what the reference arithmetic itself
+    reproduces): returns (y, dx, {parameter gradients}, [pre-norm sums per group])."""
+    import copy
+    l2 = copy.deepcopy(layer).to(dtype)
+    if hasattr(l2, "grid") and isinstance(l2.grid, torch.Tensor):
+        l2.grid = l2.grid.to(dtype)
+    xo = x.to(dtype).clone().requires_grad_(True)
+    pre = []
+    yo = oracle_forward(cfg, l2, xo, pre)
+    if go is None:
+        return yo.detach(), None, {}, pre
+    yo.backward(go.to(dtype))
+    return yo.detach(), xo.grad, {n: p.grad for n, p in l2.named_parameters() if p.grad is not None}, pre
+
+
+def check_vs_oracle(layer, cfg, x, groups=1, tag=None, scale=1.0):
+    """fwd + bwd of the HIP layer against the fp64 oracle with the same parameters.  Every tensor's tolerance is
+        max(stated, 4 x what the fp32 oracle itself achieves against fp64 on THAT tensor)
+    -- the rule of the golden fixtures (test_gpu_golden.py), with the reference's own noise measured live -- so that cases the reference
+    arithmetic cannot reproduce either (InstanceNorm over tiny, near-constant or mostly-padding planes) are judged against what it can.  No
+    flat multipliers: `scale` exists for exploration only (KAN_FUZZ_SCALE) and is 1 in every committed test.  Outputs that sit on a
+    PReLU kink (|normalised value| <= 1e-4: a 1e-7 difference flips the slope) get no upstream gradient."""
+    import copy
+    y0, _, _, pre = oracle_run(cfg, layer, x, None, torch.float64)
+    go = torch.randn(y0.shape, generator=torch.Generator().manual_seed(99))
+    if hasattr(layer, "prelus") and len(pre) == groups:
+        norms = copy.deepcopy(layer.layer_norm).double()
+        with torch.no_grad():
+            n = torch.cat([norms[g](z.detach()) for g, z in enumerate(pre)], 1)
+        go = go * (n.abs() > 1e-4).reshape(go.shape).float()
+    y32, dx32, dw32, _ = oracle_run(cfg, layer, x, go, torch.float32)
+    y64, dx64, dw64, _ = oracle_run(cfg, layer, x, go, torch.float64)
+    layer.zero_grad(set_to_none=True)
+    dev = layer.cuda()
+    xg = x.clone().cuda().requires_grad_(True)
+    y = dev(xg)
+    y.backward(go.cuda())
+    torch.cuda.synchronize()
+
+    def tol(base, a32, a64):
+        return max(base * scale, 4.0 * relerr(a32, a64))
+    errs = {"y": (relerr(y, y64), tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx64), tol(TOL_DX, dx32, dx64))}
+    scal_h, scal_r, scal_64 = [], [], []
+    for name, p_ in dev.named_parameters():
+        if name not in dw32:
+            continue
+        if p_.numel() == 1:                                       # per-group PReLU slopes: judged together (one scalar each)
+            scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dw32[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
+        else:
+            errs[name] = (relerr(p_.grad, dw64[name]), tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
+    if scal_h:
+        a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
+        errs["prelus"] = (relerr(a, b64), tol(2e-5, b, b64))
+    bad = {k_: v for k_, v in errs.items() if not v[0] <= v[1]}
+    assert not bad, f"{tag if tag is not None else cfg}: {bad}  (all: {errs})"
+    return errs

@@ -69,6 +69,58 @@ def test_kan_vgg11_step_through_rccl_reducer(gpu_lib, rccl_group):
         red.remove()
 
 
+def test_second_step_after_a_weight_update_fills_the_buckets_afresh(gpu_lib, rccl_group):
+    """always_reduce=True, a weight changed BETWEEN two steps (an optimizer-style in-place update): after finish() the sinks are
+    re-offered, the changed weight is re-packed, and the second step's bucket contents are the gradients of the NEW weights -- not a
+    stale bucket, not a stale packed layout.  Also runs one step under trace_step() and checks the diagnostics bench.py reports."""
+    import convkan_amd as K
+    from convkan_amd.parallel import BucketedGradReducer
+    torch.manual_seed(5)
+    net = torch.nn.Sequential(K.KANConv2DLayer(4, 128, 3, padding=1, base_activation=torch.nn.SiLU),
+                              K.KANConv2DLayer(128, 256, 3, padding=1, base_activation=torch.nn.SiLU)).cuda()
+    x = torch.randn(8, 4, 8, 8, device="cuda")
+
+    def plain_grads():
+        net.zero_grad(set_to_none=True)
+        net(x).square().mean().backward()
+        return [p.grad.clone() for p in net.parameters()]
+    red = BucketedGradReducer(net.parameters(), bucket_bytes=1 << 20, always_reduce=True)
+    try:
+        assert len(red.buckets) >= 2
+        net.zero_grad(set_to_none=True)
+        net(x).square().mean().backward()
+        red.finish()
+        torch.cuda.synchronize()
+        first = [b.flat.clone() for b in red.buckets]
+        with torch.no_grad():                                           # the update: every conv weight moves, through the bucket views' owners
+            for p in net.parameters():
+                if p.dim() == 4:
+                    p.add_(0.05 * torch.randn_like(p))
+        net.zero_grad(set_to_none=True)
+        out = {}
+        loss = net(x).square().mean()
+        with red.trace_step(out):
+            out["t0"] = torch.cuda.Event(enable_timing=True); out["t0"].record(torch.cuda.current_stream())
+            loss.backward()
+            red.finish()
+        second = [b.flat.clone() for b in red.buckets]
+        views = {id(p): v for b in red.buckets for p, v in zip(b.params, b.views)}
+        got = [p.grad.clone() for p in net.parameters()]
+        assert all(p.grad.data_ptr() == views[id(p)].data_ptr() for p in net.parameters())
+        assert any(not torch.equal(a, b) for a, b in zip(first, second))
+        # diagnostics: every bucket traced once, in launch order, collectives end after they became ready; exposed tail measured
+        assert sorted(d["bucket"] for d in out["buckets"]) == list(range(len(red.buckets)))
+        assert all(d["end_ms"] >= d["ready_ms"] >= 0.0 for d in out["buckets"]) and out["exposed_ms"] >= 0.0 and out["backward_end_ms"] > 0.0
+    finally:
+        red.remove()
+    want = plain_grads()                                                # the same (new) weights without any reducer
+    for (n, p), a, b in zip(net.named_parameters(), got, want):
+        if p.dim() == 4:
+            assert torch.equal(a, b), n                                 # deterministic kernels, AVG over one rank
+        else:
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12, n
+
+
 def test_shared_layer_does_not_alias_its_sink(gpu_lib):
     """A Parameter feeding two graph nodes of one backward pass: the second node must not write the sink the first one
     filled (autograd would sum two aliases of the last gradient)."""
@@ -102,3 +154,6 @@ def test_bench_launches_its_own_ranks(gpu_lib):
     doc = json.loads(lines[0])
     assert doc["rccl_ranks"] == 1 and doc["n_gpus"] == 1 and doc["launcher"].startswith("bench.py")
     assert doc["value"] > 1000 and doc["allreduce"]["bytes_per_step"] == 82964690 * 4
+    ar = doc["allreduce"]                                                # the N > 1 diagnostics (one untimed traced step, per-rank clocks)
+    assert "trace_error" not in ar and ar["exposed_ms"] >= 0.0 and len(ar["buckets"]) == ar["buckets"].__len__() and len(ar["buckets"]) >= 4
+    assert all(b["end_ms"] >= b["ready_ms"] for b in ar["buckets"]) and doc["ms_per_step_ranks"]["min"] <= doc["ms_per_step_ranks"]["max"]

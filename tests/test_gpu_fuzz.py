@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 import convkan_amd as K
-from helpers import TOL_DW, TOL_DX, TOL_Y, oracle_forward, relerr
+from helpers import check_vs_oracle
 from test_gpu_oracle import _cfg
 
 pytestmark = pytest.mark.gpu
@@ -48,61 +48,10 @@ def _draw(seed):
     return dict(fam=fam, C=C, O=O, G=G, k=kk, s=s, d=d, p=p, H=H, W=W, B=B)
 
 
-def _oracle_run(cfg, layer, x, go, dtype):
-    import copy
-    l2 = copy.deepcopy(layer).to(dtype)
-    if hasattr(l2, "grid") and isinstance(l2.grid, torch.Tensor):
-        l2.grid = l2.grid.to(dtype)
-    xo = x.to(dtype).clone().requires_grad_(True)
-    pre = []
-    yo = oracle_forward(cfg, l2, xo, pre)
-    if go is None:
-        return yo.detach(), None, {}, pre
-    yo.backward(go.to(dtype))
-    return yo.detach(), xo.grad, {n: p.grad for n, p in l2.named_parameters() if p.grad is not None}, pre
-
-
 def _check(layer, cfg, x, c):
-    y0, _, _, pre = _oracle_run(cfg, layer, x, None, torch.float64)
-    go = torch.randn(y0.shape, generator=torch.Generator().manual_seed(99))
-    if hasattr(layer, "prelus") and len(pre) == c["G"]:           # no upstream gradient on a PReLU kink: a normalised value
-        import copy                                               # within 1e-4 of 0 flips the slope for any 1e-7 difference
-        norms = copy.deepcopy(layer.layer_norm).double()
-        with torch.no_grad():
-            n = torch.cat([norms[g](z.detach()) for g, z in enumerate(pre)], 1)
-        go = go * (n.abs() > 1e-4).reshape(go.shape).float()
-    y32, dx32, dw32, _ = _oracle_run(cfg, layer, x, go, torch.float32)
-    y64, dx64, dw64, _ = _oracle_run(cfg, layer, x, go, torch.float64)
-    layer.zero_grad(set_to_none=True)
-    dev = layer.cuda()
-    xg = x.clone().cuda().requires_grad_(True)
-    y = dev(xg)
-    y.backward(go.cuda())
-    torch.cuda.synchronize()
-    # every tensor is judged against the fp64 oracle: stated tolerance, or 4 x what the fp32 oracle itself achieves on that tensor
-    # where the case is ill-conditioned (InstanceNorm over near-constant / mostly-padding planes).  KAN_FUZZ_SCALE widens the
-    # stated part for exploration; the committed value is 1.
-    scale = float(__import__("os").environ.get("KAN_FUZZ_SCALE", "1"))
-    ho, wo = dev.conv_spec().out_hw(c["H"], c["W"])
-    if ho * wo <= 4:                      # InstanceNorm over <= 4 values: x8, as the single-layer tests on the 2x2 layers (of 771 draws at x1 the one
-        scale *= 8.0                      # failure was a 2x2 output plane that is mostly padding: 1.7e-4 against 4 x the fp32 oracle's 2.4e-5)
-
-    def tol(base, a32, a64):
-        return max(base * scale, 4.0 * relerr(a32, a64))
-    errs = {"y": (relerr(y, y64), tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx64), tol(TOL_DX, dx32, dx64))}
-    scal_h, scal_r, scal_64 = [], [], []
-    for name, p_ in dev.named_parameters():
-        if name not in dw32:
-            continue
-        if p_.numel() == 1:                                       # per-group PReLU slopes: judged together (one scalar each)
-            scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dw32[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
-        else:
-            errs[name] = (relerr(p_.grad, dw64[name]), tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
-    if scal_h:
-        a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
-        errs["prelus"] = (relerr(a, b64), tol(2e-5, b, b64))
-    bad = {k_: v for k_, v in errs.items() if not v[0] <= v[1]}
-    assert not bad, f"{c}: {bad}"
+    """max(stated, 4 x the fp32 oracle's own distance from fp64) per tensor (helpers.check_vs_oracle).  KAN_FUZZ_SCALE widens the stated
+    part for exploration; the committed value is 1 and no shape class gets a multiplier of its own."""
+    check_vs_oracle(layer, cfg, x, groups=c["G"], tag=c, scale=float(__import__("os").environ.get("KAN_FUZZ_SCALE", "1")))
 
 
 _OFF = int(__import__("os").environ.get("KAN_FUZZ_OFFSET", "0"))      # KAN_FUZZ_OFFSET / _N / _FAM_N: explore other seed ranges
@@ -196,7 +145,9 @@ def test_random_1d_vs_oracle(seed, gpu_lib):
     _check(layer, cfg, x, dict(kind=kind, C=C, O=O, G=G, H=1, W=Lx, k=k, s=s_, d=d, p=p, B=B))
 
 
-THREE_D = {"bspline": "KANConv3DLayer", "rbf": "FastKANConv3DLayer", "cheby": "ChebyKANConv3DLayer"}
+THREE_D = {"bspline": "KANConv3DLayer", "rbf": "FastKANConv3DLayer", "cheby": "ChebyKANConv3DLayer",
+           # 3-D shims of the recurrence families (one shared _forward3d; Taylor holds `degree` planes, the others degree + 1) and FourierKAN
+           "taylor": "TaylorKANConv3DLayer", "lucas": "LucasKANConv3DLayer", "hermite": "HermiteKANConv3DLayer", "fourier": "FourierKANConv3DLayer"}
 
 
 @pytest.mark.parametrize("seed", range(_OFF, _OFF + int(__import__("os").environ.get("KAN_FUZZ_3D_N", "18"))))
@@ -220,8 +171,15 @@ def test_random_3d_vs_oracle(seed, gpu_lib):
             H, W = 4, 4
     B = r.choice([1, 2, 5])
     torch.manual_seed(seed)
-    layer = getattr(K, THREE_D[kind])(C, O, k, groups=G, stride=s_, dilation=d, padding=p)
-    cfg = _cfg(kind, C, O, k=k, s=s_, p=p, d=d, groups=G, degree=3, ndim=3, act="gelu" if kind == "bspline" else "silu")
+    kw3 = dict(groups=G, stride=s_, dilation=d, padding=p)
+    degree = 3
+    if kind in ("taylor", "lucas", "hermite"):
+        degree = r.choice([1, 2, 3, 4])
+        kw3["degree"] = degree
+    elif kind == "fourier":
+        kw3["grid_size"] = degree
+    layer = getattr(K, THREE_D[kind])(C, O, k, **kw3)
+    cfg = _cfg(kind, C, O, k=k, s=s_, p=p, d=d, groups=G, degree=degree, ndim=3, act="silu" if kind in ("rbf", "cheby") else "gelu")
     x = torch.randn(B, C, D, H, W) * (1.0 + (seed % 2))
     _check(layer, cfg, x, dict(kind=kind, C=C, O=O, G=G, D=D, H=H, W=W, k=k, s=s_, d=d, p=p, B=B))
 

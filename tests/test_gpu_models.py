@@ -189,14 +189,13 @@ def test_kan_vgg11_bs256_vs_oracle(gpu_lib):
             bad.append(("activation", i, act_err[i], eo))
 
     # ---- (b) each layer on the HIP model's own input / output gradient
-    full = os.environ.get("KAN_BS256_FULL", "0") == "1"          # + the fp32 oracle per layer and the noisy fp64 replica (~2 more minutes of CPU)
     stated = {"y": 1e-5, "dx": 1e-5, "w_base": 5e-5, "w_spline": 5e-5, "prelu": 5e-5}
     for i in sorted(rech):
         fh = m.features[i]
         got = {"y": rech[i]["y"], "dx": rech[i].get("dx"), "w_base": fh.base_conv[0].weight.grad, "w_spline": fh.spline_conv[0].weight.grad,
                "prelu": fh.prelus[0].weight.grad}
         ref = {}
-        for tag, lay, dt in (("f64", copy.deepcopy(o64.features[i]), torch.float64), ("f32", copy.deepcopy(o.features[i]), torch.float32))[:2 if full else 1]:
+        for tag, lay, dt in (("f64", copy.deepcopy(o64.features[i]), torch.float64), ("f32", copy.deepcopy(o.features[i]), torch.float32)):
             lay.zero_grad(set_to_none=True)
             xi = rech[i]["x"].to(dt).cpu().requires_grad_(True)
             yo = lay(xi, prelu_gate=(rech[i]["y"] > 0).cpu())
@@ -207,48 +206,41 @@ def test_kan_vgg11_bs256_vs_oracle(gpu_lib):
             if got[k] is None:
                 continue
             eh = dmax(got[k], ref["f64"][k])
-            # without the fp32 oracle's own figure (default run): the stated tolerance, x8 on the 2x2-plane layers as in the single-layer
-            # tests (measured there: the fp32 oracle itself is 4e-6 - 8e-6 from fp64, HIP 1.5e-5 - 2.4e-5)
-            eo = dmax(ref["f32"][k], ref["f64"][k]) if full else (2.0 * stated[k] if rech[i]["y"].shape[-1] == 2 else 0.0)
+            eo = dmax(ref["f32"][k], ref["f64"][k])               # what the fp32 oracle layer achieves on the same tensors
             line += f"  {k} {eh:.1e} ({eo:.1e})"
             if eh > max(stated[k], K_SPREAD * eo):
                 bad.append(("own-input", i, k, eh, eo))
         print(line + "   [HIP-vs-fp64 (oracle fp32-vs-fp64), max-normalised]")
 
-    # ---- (c) end-to-end gradients.  Default run: direction and size against fp64 with the bound the full run measured (the exact model
-    # under HIP-sized activation noise moves its conv-weight gradients by 2.4e-2 - 3.1e-2 (L2); HIP sits at 0.8e-2 - 1.1e-2, the fp32
-    # oracle at 1e-4 - 2e-3: DESIGN.md section 4).  KAN_BS256_FULL=1 re-measures that response and asserts K x it.
-    gn = None
-    if full:
-        gen = torch.Generator().manual_seed(7)
-        hooks = []
-        for i, f in enumerate(o64.features):
-            if isinstance(f, OracleKANConv2d) and act_err.get(i, 0.0) > 0.0:
-                def noisy(mod, args, i=i):
-                    a = args[0]
-                    return (a + act_err[i] * a.pow(2).mean().sqrt() * torch.randn(a.shape, generator=gen, dtype=a.dtype),)
-                hooks.append(f.register_forward_pre_hook(noisy))
-        o64.zero_grad(set_to_none=True)
-        F.cross_entropy(o64(x.double()), t).backward()
-        for h in hooks:
-            h.remove()
-        gn = [q.grad.flatten() for q in o64.parameters()]
+    # ---- (c) end-to-end gradients: the exact (fp64) model's own response to activation noise of the HIP path's measured size is
+    # re-measured on every run and K x it is the bound (the response is 2.4e-2 - 3.1e-2 (L2) on the conv weights,
+    # HIP sits at 0.8e-2 - 1.1e-2, the fp32 oracle at 1e-4 - 2e-3).
+    gen = torch.Generator().manual_seed(7)
+    hooks = []
+    for i, f in enumerate(o64.features):
+        if isinstance(f, OracleKANConv2d) and act_err.get(i, 0.0) > 0.0:
+            def noisy(mod, args, i=i):
+                a = args[0]
+                return (a + act_err[i] * a.pow(2).mean().sqrt() * torch.randn(a.shape, generator=gen, dtype=a.dtype),)
+            hooks.append(f.register_forward_pre_hook(noisy))
+    o64.zero_grad(set_to_none=True)
+    F.cross_entropy(o64(x.double()), t).backward()
+    for h in hooks:
+        h.remove()
+    gn = [q.grad.flatten() for q in o64.parameters()]
     rows = []
     for k, ((n, p), a32, a64) in enumerate(zip(m.named_parameters(), g32, g64)):
         a = p.grad.detach().double().cpu().flatten()
-        rows.append((n, dist(a, a64), dist(a32, a64), dist(gn[k], a64) if gn is not None else None, float(a64.norm()),
+        rows.append((n, dist(a, a64), dist(a32, a64), dist(gn[k], a64), float(a64.norm()),
                      float(torch.dot(a, a64) / (a.norm() * a64.norm() + 1e-300))))
     # the eight PReLU slopes are single numbers, each a sum of millions of signed terms: their individual responses scatter
     # by orders of magnitude from one noise draw to the next, so they share one bound (the largest response among them)
-    slope_bound = max(max(eo, er) for n, _, eo, er, _, _ in rows if "prelus" in n) if full else None
+    slope_bound = max(max(eo, er) for n, _, eo, er, _, _ in rows if "prelus" in n)
     for n, eh, eo, er, norm, cos in rows:
         print(f"[bs256 c] {n:34s} |g| {norm:.3e}  HIP-vs-fp64 {eh:.2e}  cosine {cos:.6f}  oracle fp32-vs-fp64 {eo:.2e}"
-              + (f"  fp64 under HIP-sized activation noise {er:.2e}" if er is not None else ""))
-        if full:
-            if eh > max(STATED["grad_norm"], K_SPREAD * (slope_bound if "prelus" in n else max(eo, er))):
-                bad.append(("gradient", n, eh, eo, er))
-        elif "prelus" not in n and (eh > 5e-2 or cos < 0.999):
-            bad.append(("gradient", n, eh, cos))
+              f"  fp64 under HIP-sized activation noise {er:.2e}")
+        if eh > max(STATED["grad_norm"], K_SPREAD * (slope_bound if "prelus" in n else max(eo, er))):
+            bad.append(("gradient", n, eh, eo, er))
     assert not bad, bad
 
 

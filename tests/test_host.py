@@ -301,3 +301,45 @@ def test_l1_l2_wrapper_hook_semantics():
     assert lin.bias.grad is not None
     with pytest.raises(ValueError):
         L1(lin, -1.0)
+
+
+def test_image_runs_never_exceed_the_launch_limit(monkeypatch):
+    """ops._image_runs: a batch above the 2 GiB launch limit is cut into the fewest equal-ish runs of whole images, and no run may itself
+    exceed the limit (B = 511 images of 8 MiB used to give 2 runs of 256 = 2^31 bytes, which kan_plan then rejected)."""
+    spec = K.KANConv2DLayer(4, 4, 3, padding=1).conv_spec()
+
+    class _X:                                                    # shape only: nothing is allocated
+        def __init__(self, *shape):
+            self.shape = shape
+    for B, C, H, W, O in [(511, 64, 256, 128, 4), (512, 64, 256, 128, 4), (7, 6, 12, 12, 10), (1000, 3, 300, 301, 64), (257, 1, 2048, 1024, 1),
+                          (3, 8, 4096, 4096, 8), (4, 8, 4096, 4096, 8), (255, 64, 256, 128, 64)]:
+        Ho, Wo = spec.out_hw(H, W)
+        per_image = 4 * max(C * H * W, O * Ho * Wo)
+        n = ops._image_runs(spec, _X(B, C, H, W), O)
+        if B * per_image <= ops.MAX_TENSOR_BYTES:
+            assert n is None
+            continue
+        assert n is not None and 1 <= n and n * per_image <= ops.MAX_TENSOR_BYTES, (B, n, per_image)
+        runs = -(-B // n)
+        assert runs == -(-B // (ops.MAX_TENSOR_BYTES // per_image)), (B, n, runs)        # the fewest runs that fit
+        assert n - (B - (runs - 1) * n) < runs + n // 2 or runs == 1                      # equal-ish: the last run is not a sliver by construction
+    monkeypatch.setattr(ops, "MAX_TENSOR_BYTES", 4 * 4 * 8 * 8 - 1)                        # one image above the limit raises
+    with pytest.raises(L.KanConvError):
+        ops._image_runs(spec, _X(2, 4, 8, 8), 4)
+
+
+def test_taylor_3d_shim_sizes_its_basis_like_the_2d_layer():
+    """TaylorKANConv3DLayer holds `degree` planes (taylor_kan_layers.py compute_taylor_basis), not degree + 1: the shared 3-D forward must
+    build its basis from the same count as conv_spec() (it used degree + 1 and indexed past the coefficient list)."""
+    lay = K.TaylorKANConv3DLayer(2, 4, 3, degree=3, padding=1)
+    assert lay.poly_conv[0].weight.shape[1] == 2 * 3 and lay.conv_spec().n_basis == 3
+    seen = {}
+    import convkan_amd.layers.poly_layers as PL
+    orig = PL.conv3d_stage
+    try:
+        PL.conv3d_stage = lambda kw, *a, **k: seen.update(kw) or (_ for _ in ()).throw(RuntimeError("stop"))
+        with pytest.raises(RuntimeError, match="stop"):
+            lay._forward3d(torch.randn(1, 2, 4, 4, 4))
+    finally:
+        PL.conv3d_stage = orig
+    assert seen["n_basis"] == 3 and len(seen["table"]) == len(lay.conv_spec().table)

@@ -132,22 +132,42 @@ def train_step_timing(model, x, t, steps, warmup):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def csrc_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: the identity of the code a counter profile describes."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "convolutional-kan-for-image-classification_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        with open(os.path.join(d, fn), "rb") as f:
+            h.update(fn.encode()); h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def profiled(kernel: str):
     """Committed counter evidence for a kernel family: HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes) and the
-    matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES pass), newest round first; (None, None, None) if absent."""
+    matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES pass).  A profile is used only if it records the csrc hash of the kernels that
+    are built NOW (tools/pmc_report.py writes `csrc_sha16`): counters of an older kernel source are refused, not quoted --
+    (None, "stale: ...", None) then."""
     fam = kernel.split("/")[0]
     traffic = busy = src = None
-    for rnd in ("r02", "r01"):
+    now = csrc_sha16()
+    for rnd in ("r03",):
         try:
             with open(os.path.join(ROOT, "profiles", f"{rnd}_hbm_traffic.json")) as f:
-                traffic = round(json.load(f)["kernels"][fam]["hbm_bytes_per_launch_corrected"])
+                doc = json.load(f)
+            if doc.get("csrc_sha16") != now:
+                src = f"stale: profiles/{rnd}_hbm_traffic.json was taken on csrc {doc.get('csrc_sha16')}, built now {now}"
+                continue
+            traffic = round(doc["kernels"][fam]["hbm_bytes_per_launch_corrected"])
             src = f"profiles/{rnd}_hbm_traffic.json"
             break
         except (OSError, KeyError, ValueError):
             continue
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_mfma_busy.json")) as f:
-            busy = json.load(f)["kernels"][fam]
+        with open(os.path.join(ROOT, "profiles", "r03_mfma_busy.json")) as f:
+            doc = json.load(f)
+        if doc.get("csrc_sha16") == now:
+            busy = doc["kernels"][fam]
     except (OSError, KeyError, ValueError):
         pass
     return traffic, src, busy
@@ -435,7 +455,8 @@ def main():
         if reducer is not None:
             out["allreduce"] = {"buckets": len(reducer.buckets), "bucket_mb": args.bucket_mb,
                                 "bytes_per_step": sum(b.flat.numel() * 4 for b in reducer.buckets), "op": "avg, side stream, reverse order"}
-            out["allreduce"].update(trace)               # exposed_ms, backward_end_ms, per-bucket ready / start / end offsets (rank 0, one untimed step)
+            # exposed_ms, backward_end_ms, per-bucket ready / start / end offsets (rank 0, one untimed step)
+            out["allreduce"].update({("bucket_trace" if k == "buckets" else k): v for k, v in trace.items()})
             out["ms_per_step_ranks"] = {"min": round(min(per_rank) / args.steps * 1e3, 3), "max": round(max(per_rank) / args.steps * 1e3, 3),
                                         "all": [round(v / args.steps * 1e3, 3) for v in per_rank]}
         aux = world == 1 and not use_dist and args.workload == "kan_vgg11" and not args.no_aux

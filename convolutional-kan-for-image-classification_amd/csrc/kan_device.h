@@ -19,6 +19,26 @@ struct DevBasis {            // by-value kernel argument
     const float* ctab;       // device-memory parameters: ReLU-KAN per-channel phases [C][2][nb]; Gram coefficients [nb]
 };
 
+// ---------------------------------------------------------------- transcendentals of the hot loops
+// The staging code and the bwd-data epilogue evaluate exp / reciprocal / tanh through the hardware's v_exp_f32 / v_rcp_f32 (1 ulp each):
+// on gfx950 every vector instruction next to the fp32 MFMAs is matrix time, and libm's expf / IEEE division are ~10 / ~8 instructions.
+// -DKAN_EXACT_TRANSCENDENTALS builds the same kernels on libm-accurate expf / tanhf and IEEE division instead -- a measurement build
+// (tools/exact_ab.py: what the fast forms cost in accuracy, what the exact ones cost in time), never the shipped library.
+//   kan_exp2k(x, K) = 2^(x K) with K a compile-time multiple of log2(e): i.e. exp(x * (K ln 2)), K ln 2 in {-1, 2, -1/2} exactly
+#ifdef KAN_EXACT_TRANSCENDENTALS
+__device__ __forceinline__ float kan_exp2k(float x, float K) { return expf(x * (float)((double)K * 0.69314718055994530942)); }
+__device__ __forceinline__ float kan_rcp(float x) { return 1.0f / x; }
+__device__ __forceinline__ float kan_tanh_fast(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float kan_exp2k(float x, float K) { return __builtin_amdgcn_exp2f(x * K); }
+__device__ __forceinline__ float kan_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// tanh through hardware exp2 / rcp: (e - 1) / (e + 1), e = exp(2x) (argument clamped: e stays finite), |err| ~ 1e-7 absolute
+__device__ __forceinline__ float kan_tanh_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(fminf(x, 40.f) * 2.88539008177792681472f);
+    return (e - 1.0f) * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+#endif
+
 // ---------------------------------------------------------------- activations
 // kan_layers.py:199 / fast_kan_layers.py:103: base_activation(x); torch CPU formulas.
 __device__ __forceinline__ float kan_act(int act, float x) {
@@ -65,7 +85,7 @@ __device__ __forceinline__ float kan_act_grad(int act, float x) {
 // matrix time; x * rcp(1 + exp2(-x*log2e)) is 5 instructions instead of ~25 for x / (1 + expf(-x)), at <= 4e-7
 // relative error for |x| <= 6 (hardware exp2/rcp are 1 ulp).
 __device__ __forceinline__ float kan_act_fast(int act, float x) {
-    if (act == KAN_ACT_SILU) return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896340736f));
+    if (act == KAN_ACT_SILU) return x * kan_rcp(1.0f + kan_exp2k(x, -1.44269504088896340736f));
     return kan_act(act, x);
 }
 
@@ -95,30 +115,39 @@ __device__ __forceinline__ bool bspline_uniform(int S, float x, const float* kn,
     // S >= 1: a cell picked one off at a knot (x within an ulp of g_i) only shifts u to ~0 or ~1 of the neighbour,
     // where the pieces agree to O(ulp) (C^0 for S=1 ... C^2 for S=3); u is clamped below.
     j0 = i - S;
-    const float u = fminf(fmaxf((x - gi) * inv_h, 0.f), 1.f);
-    const float v = 1.f - u;
+#ifdef KAN_EXACT_TRANSCENDENTALS
+    // measurement build: u and the pieces in double on the fp32 knots themselves, rounded once (<= 0.5 ulp per plane)
+    typedef double real;
+    const real ih = 1.0 / ((double)kn[i + 1] - (double)gi);
+    const real u = fmin(fmax(((double)x - (double)gi) * ih, 0.0), 1.0);
+#else
+    typedef float real;
+    const real ih = inv_h;
+    const real u = fminf(fmaxf((x - gi) * inv_h, 0.f), 1.f);
+#endif
+    const real v = (real)1 - u;
     N[0] = N[1] = N[2] = N[3] = 0.f;
     if (!DERIV) {
         if (S == 0) { N[0] = 1.f; }
-        else if (S == 1) { N[0] = v; N[1] = u; }
-        else if (S == 2) { N[0] = 0.5f * v * v; N[1] = 0.5f * (1.f + 2.f * u * v); N[2] = 0.5f * u * u; }
+        else if (S == 1) { N[0] = (float)v; N[1] = (float)u; }
+        else if (S == 2) { N[0] = (float)((real)0.5 * v * v); N[1] = (float)((real)0.5 * ((real)1 + (real)2 * u * v)); N[2] = (float)((real)0.5 * u * u); }
         else {
-            const float u2 = u * u, u3 = u2 * u;
-            const float k6 = 1.f / 6.f;
-            N[0] = k6 * v * v * v;
-            N[1] = k6 * (3.f * u3 - 6.f * u2 + 4.f);
-            N[2] = k6 * (-3.f * u3 + 3.f * u2 + 3.f * u + 1.f);
-            N[3] = k6 * u3;
+            const real u2 = u * u, u3 = u2 * u;
+            const real k6 = (real)1 / (real)6;
+            N[0] = (float)(k6 * v * v * v);
+            N[1] = (float)(k6 * ((real)3 * u3 - (real)6 * u2 + (real)4));
+            N[2] = (float)(k6 * ((real)-3 * u3 + (real)3 * u2 + (real)3 * u + (real)1));
+            N[3] = (float)(k6 * u3);
         }
     } else {
-        if (S == 1) { N[0] = -inv_h; N[1] = inv_h; }
-        else if (S == 2) { N[0] = -v * inv_h; N[1] = (1.f - 2.f * u) * inv_h; N[2] = u * inv_h; }
+        if (S == 1) { N[0] = (float)-ih; N[1] = (float)ih; }
+        else if (S == 2) { N[0] = (float)(-v * ih); N[1] = (float)(((real)1 - (real)2 * u) * ih); N[2] = (float)(u * ih); }
         else if (S == 3) {
-            const float u2 = u * u, hh = 0.5f * inv_h;
-            N[0] = -hh * v * v;
-            N[1] = hh * (3.f * u2 - 4.f * u);
-            N[2] = hh * (-3.f * u2 + 2.f * u + 1.f);
-            N[3] = hh * u2;
+            const real u2 = u * u, hh = (real)0.5 * ih;
+            N[0] = (float)(-hh * v * v);
+            N[1] = (float)(hh * ((real)3 * u2 - (real)4 * u));
+            N[2] = (float)(hh * ((real)-3 * u2 + (real)2 * u + (real)1));
+            N[3] = (float)(hh * u2);
         }
     }
     return true;

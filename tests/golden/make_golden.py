@@ -10,7 +10,7 @@ box).  For every case it
   4. freezes inputs, every state_dict tensor, outputs and all gradients into an .npz.
 
 Usage:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py            (everything)
-        ... make_golden.py --mlp-only | --poly-only [--kind=lucas] | --1d-only | --relu-only | --gram-only | --3d-only | --model-only
+        ... make_golden.py --mlp-only | --poly-only [--kind=lucas] | --1d-only | --relu-only | --gram-only | --3d-only | --model-only | --dropin-only
         (regenerate one fixture family; every family has its own seed range, so the others stay byte-identical)
 """
 import importlib
@@ -755,7 +755,62 @@ def model_cases():
     run_model("cheby_alexnet", alex, xa, torch.tensor([5]))
 
 
+def dropin_check():
+    """north_star: the factory "drops into kan_vgg.py / kan_alexnet.py unchanged".  Imports the reference's model files UNMODIFIED
+    (models/kan_vgg.py:73-101,119-130; models/kan_alexnet.py:54-69,120-126), builds each model twice -- with the reference's own
+    CONV_KAN_FACTORY and with this repo's swapped into the module -- and requires identical state_dict keys / shapes and a strict
+    load_state_dict round trip both ways, plus the same for this repo's own model counterparts (convkan_amd.models).  The outcome is
+    recorded in tests/golden/dropin_check.json, which the CPU suite reads (tests/test_host.py): the reference cannot travel."""
+    import hashlib
+    import convkan_amd as K
+    from convkan_amd import models as OURS
+    kv, ka = import_ref_models()
+    kv.cfgs["VGG11"] = O.VGG11_CFG
+    builds = {
+        "vgg11_kan_linear": (kv, lambda m: m.vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear"),
+                             lambda: OURS.vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear")),
+        "vgg11_kan_kanhead": (kv, lambda m: m.vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="KAN"),
+                              lambda: OURS.vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="KAN")),
+        "vgg16small_fastkan": (kv, lambda m: m.vggkan(3, 10, arch="VGG16_small", kan_conv="FastKAN", classifier_type="Linear"),
+                               lambda: OURS.vggkan(3, 10, arch="VGG16_small", kan_conv="FastKAN", classifier_type="Linear")),
+        "alexnet_chebykan_deg4": (ka, lambda m: m.alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4),
+                                  lambda: OURS.alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4)),
+        "alexnet_kan_kanhead_small": (ka, lambda m: m.alexnet_kan(num_classes=10, kan_conv="KAN", classifier_type="KAN", arch="small", grid_size=4),
+                                      lambda: OURS.alexnet_kan(num_classes=10, kan_conv="KAN", classifier_type="KAN", arch="small", grid_size=4)),
+    }
+    record = {"note": "reference model files imported unmodified; CONV_KAN_FACTORY swapped for convkan_amd's; generated by tests/golden/make_golden.py --dropin-only",
+              "reference_files": {f: hashlib.sha256(open(os.path.join(REF, f), "rb").read()).hexdigest()[:16]
+                                  for f in ("models/kan_vgg.py", "models/kan_alexnet.py", "layers/kan_conv.py")},
+              "models": {}}
+    for name, (mod, build_ref, build_ours) in builds.items():
+        ref_factory = mod.CONV_KAN_FACTORY
+        torch.manual_seed(0)
+        ref = build_ref(mod)
+        mod.CONV_KAN_FACTORY = K.CONV_KAN_FACTORY                       # the drop-in: the reference's model code, this repo's layers
+        try:
+            torch.manual_seed(0)
+            hyb = build_ref(mod)
+        finally:
+            mod.CONV_KAN_FACTORY = ref_factory
+        ours = build_ours()
+        sig = lambda m: [(k, list(v.shape)) for k, v in m.state_dict().items()]
+        assert sig(ref) == sig(hyb), f"{name}: reference model on this repo's factory differs from the reference: {set(map(str, sig(ref))) ^ set(map(str, sig(hyb)))}"
+        assert sig(ref) == sig(ours), f"{name}: this repo's model counterpart differs from the reference"
+        assert [n for n, _ in ref.named_parameters()] == [n for n, _ in hyb.named_parameters()] == [n for n, _ in ours.named_parameters()]
+        hyb.load_state_dict(ref.state_dict(), strict=True); ref.load_state_dict(hyb.state_dict(), strict=True)
+        ours.load_state_dict(ref.state_dict(), strict=True); ref.load_state_dict(ours.state_dict(), strict=True)
+        n_hip = sum(isinstance(m, K.layers.conv_layers._HipLayer) for m in hyb.modules())
+        assert n_hip > 0, f"{name}: no layer of this repo was built by the reference's model code"
+        record["models"][name] = {"state_dict": sig(ref), "parameters": sum(p.numel() for p in ref.parameters()), "hip_layers_built_by_reference_code": n_hip,
+                                  "class_name": getattr(ref, "name", type(ref).__name__), "strict_round_trip": True}
+        print(f"drop-in {name}: {len(sig(ref))} state_dict entries, {record['models'][name]['parameters']} parameters, {n_hip} HIP layers built by the reference's model code: OK")
+    with open(os.path.join(HERE, "dropin_check.json"), "w") as f:
+        json.dump(record, f, indent=1)
+
+
 def main():
+    if "--dropin-only" in sys.argv:                 # the reference's unchanged model files on this repo's factory
+        return dropin_check()
     if "--mlp-only" in sys.argv:                    # regenerate just the MLP KANLayer fixtures
         return mlp_cases()
     if "--poly-only" in sys.argv:                   # regenerate just the polynomial-family fixtures
@@ -789,6 +844,7 @@ def main():
     hostact_cases()
     wav_cases()
     model_cases()
+    dropin_check()
     print(f"total layer fixtures: {total / 1e6:.2f} MB")
 
 

@@ -174,7 +174,7 @@ def oracle_run(cfg, layer, x, go, dtype):
     return yo.detach(), xo.grad, {n: p.grad for n, p in l2.named_parameters() if p.grad is not None}, pre
 
 
-def check_vs_oracle(layer, cfg, x, groups=1, tag=None, scale=1.0):
+def check_vs_oracle(layer, cfg, x, groups=1, tag=None, scale=1.0, assert_ok=True):
     """fwd + bwd of the HIP layer against the fp64 oracle with the same parameters.  Every tensor's tolerance is
         max(stated, 4 x what the fp32 oracle itself achieves against fp64 on THAT tensor)
     -- the rule of the golden fixtures (test_gpu_golden.py), with the reference's own noise measured live -- so that cases the reference
@@ -198,9 +198,10 @@ def check_vs_oracle(layer, cfg, x, groups=1, tag=None, scale=1.0):
     y.backward(go.cuda())
     torch.cuda.synchronize()
 
-    def tol(base, a32, a64):
-        return max(base * scale, 4.0 * relerr(a32, a64))
-    errs = {"y": (relerr(y, y64), tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx64), tol(TOL_DX, dx32, dx64))}
+    def tol(base, a32, a64):                                      # (tolerance, the fp32 oracle's own distance from fp64)
+        o = relerr(a32, a64)
+        return max(base * scale, 4.0 * o), o
+    errs = {"y": (relerr(y, y64), *tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx64), *tol(TOL_DX, dx32, dx64))}
     scal_h, scal_r, scal_64 = [], [], []
     for name, p_ in dev.named_parameters():
         if name not in dw32:
@@ -208,10 +209,10 @@ def check_vs_oracle(layer, cfg, x, groups=1, tag=None, scale=1.0):
         if p_.numel() == 1:                                       # per-group PReLU slopes: judged together (one scalar each)
             scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dw32[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
         else:
-            errs[name] = (relerr(p_.grad, dw64[name]), tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
+            errs[name] = (relerr(p_.grad, dw64[name]), *tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
     if scal_h:
         a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
-        errs["prelus"] = (relerr(a, b64), tol(2e-5, b, b64))
+        errs["prelus"] = (relerr(a, b64), *tol(2e-5, b, b64))
     bad = {k_: v for k_, v in errs.items() if not v[0] <= v[1]}
-    assert not bad, f"{tag if tag is not None else cfg}: {bad}  (all: {errs})"
+    assert not (bad and assert_ok), f"{tag if tag is not None else cfg}: (error, tolerance, fp32 oracle's own error) {bad}  (all: {errs})"
     return errs

@@ -343,3 +343,28 @@ def test_taylor_3d_shim_sizes_its_basis_like_the_2d_layer():
     finally:
         PL.conv3d_stage = orig
     assert seen["n_basis"] == 3 and len(seen["table"]) == len(lay.conv_spec().table)
+
+
+def test_reference_model_files_build_unchanged_on_this_factory():
+    """tests/golden/dropin_check.json is written in the build container by `make_golden.py --dropin-only`: the reference's UNMODIFIED
+    models/kan_vgg.py / kan_alexnet.py, with CONV_KAN_FACTORY swapped for this repo's, gave the reference's own state_dict keys / shapes
+    and a strict load_state_dict round trip both ways (north_star: "drops into kan_vgg.py / kan_alexnet.py unchanged").  The reference
+    cannot travel, so here the record is checked against what this repo's layers and model counterparts build TODAY: a layer change
+    that alters a key or a shape fails this test until the drop-in check has been re-run against the reference."""
+    import json
+    from convkan_amd.models import alexnet_kan, vggkan
+    with open(os.path.join(ROOT, "tests", "golden", "dropin_check.json")) as f:
+        rec = json.load(f)
+    assert set(rec["reference_files"]) == {"models/kan_vgg.py", "models/kan_alexnet.py", "layers/kan_conv.py"}
+    build = {"vgg11_kan_linear": lambda: vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="Linear"),
+             "vgg11_kan_kanhead": lambda: vggkan(3, 10, arch="VGG11", kan_conv="KAN", classifier_type="KAN"),
+             "vgg16small_fastkan": lambda: vggkan(3, 10, arch="VGG16_small", kan_conv="FastKAN", classifier_type="Linear"),
+             "alexnet_chebykan_deg4": lambda: alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4),
+             "alexnet_kan_kanhead_small": lambda: alexnet_kan(num_classes=10, kan_conv="KAN", classifier_type="KAN", arch="small", grid_size=4)}
+    assert set(rec["models"]) == set(build)
+    for name, mk in build.items():
+        r = rec["models"][name]
+        assert r["strict_round_trip"] is True and r["hip_layers_built_by_reference_code"] > 0
+        m = mk()
+        assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, list(s)) for k, s in r["state_dict"]], name
+        assert sum(p.numel() for p in m.parameters()) == r["parameters"] and getattr(m, "name", type(m).__name__) == r["class_name"], name

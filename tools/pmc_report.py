@@ -28,12 +28,16 @@ def mean(v):
 
 a, b, f, w = (load(p) for p in sys.argv[1:5])
 prefix = sys.argv[5]
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench                                   # (torch-free import) csrc_sha16: the kernel sources these counters describe; bench.profiled() refuses any other
+SHA = sys.argv[6] if len(sys.argv) > 6 else bench.csrc_sha16()
 busy = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes) over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                 "--no-aux` (KAN-VGG11, bs 256: every conv-kernel launch of 3 steps); mean per launch of each template instance.  "
                 "mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs); valu_per_mfma = (SQ_INSTS_VALU - "
                 "SQ_INSTS_MFMA) / SQ_INSTS_MFMA (wave instructions); wait_any / wait_inst / active = share of SQ_WAVE_CYCLES-like wave "
                 "time parked at s_waitcnt or a barrier / stalled at issue / issuing (pass B counters over their sum).",
-        "instances": {}, "kernels": {}}
+        "csrc_sha16": SHA, "instances": {}, "kernels": {}}
 fam_acc = collections.defaultdict(lambda: [0.0, 0.0])
 for k in sorted(a):
     ca, cb = a[k], b.get(k, {})
@@ -62,7 +66,7 @@ json.dump(busy, open(prefix + "_mfma_busy.json", "w"), indent=1)
 traffic = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over the same command, mean per launch over all "
                    "launches of the kernel family (all 8 KAN-VGG11 layers, bs 256).  Correction per MI355X_MICROARCH.md section HBM: bytes = "
                    "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (FETCH_SIZE under-reports wide streaming reads by 2x on gfx950; the 4-byte gathers are "
-                   "uncalibrated, so this is an upper estimate of the read side; Infinity-Cache hits are counted).", "kernels": {}}
+                   "uncalibrated, so this is an upper estimate of the read side; Infinity-Cache hits are counted).", "csrc_sha16": SHA, "kernels": {}}
 famf, famw = collections.defaultdict(list), collections.defaultdict(list)
 for k, c in f.items():
     famf[re.sub(r"<.*", "", k)] += c["FETCH_SIZE"]

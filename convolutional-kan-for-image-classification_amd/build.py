@@ -24,9 +24,12 @@ def _stale() -> bool:
 def build_library(force: bool = False, verbose: bool = False, defines=(), output: str = None) -> str:
     """Compile csrc/kanconv.hip -> libkanconv.so (skipped when up to date).  Returns the .so path.
     `defines` / `output`: measurement variants only (e.g. ("KAN_EXACT_TRANSCENDENTALS",) -> libkanconv_exact.so for tools/exact_ab.py);
-    a variant is always rebuilt and never replaces the shipped library."""
+    a variant never replaces the shipped library."""
     if defines or output:
-        return _compile(list(defines), output or os.path.join(_HERE, "libkanconv_" + "_".join(d.lower() for d in defines) + ".so"), verbose)
+        out = output or os.path.join(_HERE, "libkanconv_" + "_".join(d.lower() for d in defines) + ".so")
+        if not force and os.path.exists(out) and os.path.getmtime(out) > max(os.path.getmtime(f) for f in SOURCES + HEADERS):
+            return out                                # built in the container, travelled with the snapshot
+        return _compile(list(defines), out, verbose)
     if not force and not _stale():
         return OUTPUT
     # several ranks of one node may get here at once: serialise on a lock file, re-check, and publish atomically

@@ -31,7 +31,8 @@ class KanBasis(C.Structure):
 
 class KanPlan(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("P", "K", "IPC", "KC", "Kpad", "Opad", "fwd_splits", "bwd_data_splits", "bwd_weight_splits",
-                                          "fwd_target", "bwd_data_target", "bwd_weight_target", "x_pm_wanted", "dz_pm_wanted", "bwd_weight_expanded", "row_blocks", "e_pm_wanted", "fwd_expanded", "fwd_halo", "bwd_weight_halo")] + \
+                                          "fwd_target", "bwd_data_target", "bwd_weight_target", "x_pm_wanted", "dz_pm_wanted", "bwd_weight_expanded", "row_blocks", "e_pm_wanted", "fwd_expanded", "fwd_halo", "bwd_weight_halo",
+                                          "fwd_band", "bwd_weight_band")] + \
                [(n, C.c_longlong) for n in ("packed_weight_bytes", "bwd_data_weight_bytes", "fwd_slab_elems", "bwd_data_slab_elems",
                                             "bwd_weight_slab_elems", "e_pm_elems")]
 

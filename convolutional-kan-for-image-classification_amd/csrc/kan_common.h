@@ -352,4 +352,35 @@ __device__ __forceinline__ void glds16(const float* gsrc, float* lds_base) {
                                      (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
 }
 
+// ---------------------------------------------------------------- small host helpers (plan arithmetic, kernel-argument structs)
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+inline int ngroups(const KanGeom* g) { return g->groups > 0 ? g->groups : 1; }
+inline int log2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
+
+inline DevGeom dev_geom(const KanGeom* g) {
+    DevGeom d{g->B, g->C, g->H, g->W, g->O, g->Ho, g->Wo, g->kh, g->kw, g->sh, g->sw, g->ph, g->pw, g->dh, g->dw, -1, -1, 0, -1,
+              g->x_bstride, g->y_bstride};
+    const int a = log2_exact(g->Ho * g->Wo), b = log2_exact(g->Wo);
+    if (a >= 0 && b >= 0) { d.howo_shift = a; d.wo_shift = b; }
+    d.b_shift = log2_exact(g->B);
+    d.divC = make_fastdiv(g->C); d.divKw = make_fastdiv(g->kw);
+    return d;
+}
+inline DevBasis dev_basis(const KanBasis* b) {
+    DevBasis d;
+    d.kind = b->kind; d.nb = b->n_basis; d.order = b->order; d.act = b->act;
+    d.hb = b->act != KAN_ACT_NONE ? 1 : 0; d.P = b->n_basis + d.hb;
+    d.p0 = b->p0; d.p1 = b->p1; d.inv_h = 0.f; d.g0 = 0.f; d.gN = 0.f;
+    for (int i = 0; i < KAN_MAX_TABLE; ++i) d.tab[i] = b->table[i];
+    d.ctab = (b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) ? b->chan_table : nullptr;
+    if (b->kind == KAN_BASIS_BSPLINE) {
+        int nk = b->n_basis + b->order + 1;
+        float span = b->table[nk - 1] - b->table[0];
+        d.inv_h = span > 0.f ? (float)(nk - 1) / span : 0.f;
+        d.g0 = b->table[0]; d.gN = b->table[nk - 1];
+    }
+    return d;
+}
+
 }  // namespace

@@ -50,13 +50,18 @@ namespace {
 // divT / divNb / divIPC / divP: magic numbers for the per-element index divisions below.  With plain `/` the three layout
 // kernels spent ~100 VALU instructions per element on integer division and were ALU-bound, not HBM-bound (0.81 ms of a
 // 17.4 ms KAN-VGG11 step for 1 GB of traffic).
-struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair, cmajor; FastDiv divT, divNb, divIPC, divP; };
+struct PackGeo { int O, C, T, P, hb, nb, IPC, KC, Opad, pair, cmajor; FastDiv divT, divNb, divIPC, divP;
+                 int band; short tap_step[KAN_BAND_MAX_TAPS], tap_nt[KAN_BAND_MAX_TAPS]; };        // band order (kan_internal.h): IPC = channels per group
 
 // Row of (tap, channel c, plane p) in the forward layout.  pair == 0: tap-major items as described above.  pair == 1 (the
 // halo forward kernel, P = 9, C even): a step of KC = 18 rows is one tap of a channel PAIR, row 2p + (c & 1), steps
 // ordered (c / 2, tap) -- so that the two k-rows of an MFMA k-pair are the same plane of two channels, a fixed LDS
 // distance apart in the halo tile.
 __device__ __forceinline__ int wp_row(const PackGeo& q, int tap, int c, int p) {
+    if (q.band) {                                     // band kernels: step (phase, channel group, tap of the phase), row = (c % IPC) * P + p
+        const int grp = fastdiv(c, q.divIPC);
+        return (q.tap_step[tap] + grp * q.tap_nt[tap]) * q.KC + (c - grp * q.IPC) * q.P + p;
+    }
     if (q.pair) return ((c >> 1) * q.T + tap) * q.KC + 2 * p + (c & 1);
     if (q.cmajor) return (c * q.T + tap) * q.P + p;   // flat channel-major order of the halo weight-gradient kernel
     const int item = tap * q.C + c;                   // tap-major: all channels of a tap are contiguous in the depth axis
@@ -2413,10 +2418,6 @@ __global__ __launch_bounds__(NT) void k_in_prelu_bwd_regs(const float* __restric
 }
 
 // ============================================================================ host side
-int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
-int round_up(int a, int b) { return (a + b - 1) / b * b; }
-
-int ngroups(const KanGeom* g) { return g->groups > 0 ? g->groups : 1; }
 
 int check(const KanGeom* g, const KanBasis* b) {
     if (!g || !b) return fail("null geometry/basis");
@@ -2458,17 +2459,6 @@ int check(const KanGeom* g, const KanBasis* b) {
     return 0;
 }
 
-int log2_exact(int v) { int s = 0; while ((1 << s) < v) ++s; return (1 << s) == v ? s : -1; }
-
-DevGeom dev_geom(const KanGeom* g) {
-    DevGeom d{g->B, g->C, g->H, g->W, g->O, g->Ho, g->Wo, g->kh, g->kw, g->sh, g->sw, g->ph, g->pw, g->dh, g->dw, -1, -1, 0, -1,
-              g->x_bstride, g->y_bstride};
-    const int a = log2_exact(g->Ho * g->Wo), b = log2_exact(g->Wo);
-    if (a >= 0 && b >= 0) { d.howo_shift = a; d.wo_shift = b; }
-    d.b_shift = log2_exact(g->B);
-    d.divC = make_fastdiv(g->C); d.divKw = make_fastdiv(g->kw);
-    return d;
-}
 // Position-major pixel order (and with it tap skipping) is offered on small padded planes (<= 16 positions: 31 % of
 // the products are dead on 4x4, 56 % on 2x2).  Lanes then walk images, so the kernels must be given the [C*H*W][B]
 // copies of their gathered inputs (kan_position_major); without a copy they stay on the image-major path (on NCHW the
@@ -2493,22 +2483,6 @@ bool want_pix_major(const KanGeom* g, const KanBasis* b, int which) {
     const int plane = which == PM_BWD_DATA ? g->H * g->W : g->Ho * g->Wo;
     const int limit = which == PM_BWD_WEIGHT ? 16 : (which == PM_FWD && pmdma_fwd_shape(g, b) && tuning_on("KAN_PMDMA_FWD16")) ? 16 : 4;
     return b->kind != KAN_BASIS_RBF && plane <= limit && g->kh * g->kw <= 32 && (g->ph > 0 || g->pw > 0) && g->B >= 16;
-}
-
-DevBasis dev_basis(const KanBasis* b) {
-    DevBasis d;
-    d.kind = b->kind; d.nb = b->n_basis; d.order = b->order; d.act = b->act;
-    d.hb = b->act != KAN_ACT_NONE ? 1 : 0; d.P = b->n_basis + d.hb;
-    d.p0 = b->p0; d.p1 = b->p1; d.inv_h = 0.f; d.g0 = 0.f; d.gN = 0.f;
-    for (int i = 0; i < KAN_MAX_TABLE; ++i) d.tab[i] = b->table[i];
-    d.ctab = (b->kind == KAN_BASIS_RELU || b->kind == KAN_BASIS_GRAM) ? b->chan_table : nullptr;
-    if (b->kind == KAN_BASIS_BSPLINE) {
-        int nk = b->n_basis + b->order + 1;
-        float span = b->table[nk - 1] - b->table[0];
-        d.inv_h = span > 0.f ? (float)(nk - 1) / span : 0.f;
-        d.g0 = b->table[0]; d.gN = b->table[nk - 1];
-    }
-    return d;
 }
 
 // Split-K factor.  The conv kernels keep 4 workgroups per CU resident (1024 on the chip), so a grid of W workgroups
@@ -2583,6 +2557,21 @@ bool halo_fwd(const KanGeom* g, const KanBasis* b) {
     if (want_pix_major(g, b, PM_FWD)) return false;
     const int W = g->W, H = g->H;
     return (W == 32 && H % 4 == 0) || (W == 16 && H % 8 == 0) || (W == 8 && H == 8) || (W == 4 && H == 4);
+}
+// Band forward kernel (kan_direct.hip): the layers that would otherwise run the tap-major kernel on 64-output tiles -- few input channels
+// (a model's first layer: the whole GEMM depth is a few hundred rows and re-expanding the input once per tap is most of the kernel) or an
+// output count that fills no 128-wide tile (64 -> 192) -- with a compile-time basis spec.  Any kernel size, stride, dilation, padding.
+bool dw_direct(const KanGeom* g, const KanBasis* b);
+bool band_fwd(const KanGeom* g, const KanBasis* b, KanBandCfg* out = nullptr) {
+    const int f = fast_variant(b);
+    if (tuning_off("KAN_BAND") || !(f >= 1 && f <= 6)) return false;
+    if (b->kind == KAN_BASIS_POLY && b->order == 0) return false;            // (LegendreKAN: second input tensor; keep it on the tap-major kernel for now)
+    if (dw_direct(g, b) || want_pix_major(g, b, PM_FWD) || halo_fwd(g, b)) return false;
+    if (!(g->C <= 3 || round_up(g->O, 64) % 128 != 0)) return false;
+    KanBandCfg c;
+    kan_band_cfg(g, b, f, &c);
+    if (out) *out = c;
+    return c.ok != 0;
 }
 struct FwdCfg { int TO, TP, tiles_o, tiles_p, chunks, splits, slots; };
 FwdCfg fwd_cfg(const KanGeom* g, const KanBasis* b, const KanPlan& pl) {
@@ -2793,6 +2782,9 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         if (halo_fwd(g, b)) { pl->KC = 2 * pl->P; pl->IPC = 2; }      // pair order: one step = one tap of a channel pair, no pad rows
     }
     pl->Kpad = ceil_div(g->C * T, pl->IPC) * pl->KC;
+    KanBandCfg band;
+    const bool use_band = band_fwd(g, b, &band);
+    if (use_band) { pl->KC = band.NPLE; pl->IPC = band.NG; pl->Kpad = band.n_steps * band.NPLE; }      // band order: steps of even(NG * P) rows
     pl->Opad = round_up(g->O, 64);
     const int G = ngroups(g);
     pl->packed_weight_bytes = (long long)G * pl->Kpad * pl->Opad * 4;
@@ -2801,7 +2793,8 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->fwd_slab_elems = (long long)g->B * g->y_bstride;
     pl->bwd_data_slab_elems = (long long)g->B * g->x_bstride;
     pl->bwd_weight_slab_elems = (long long)G * pl->K * pl->Opad;
-    pl->fwd_splits = fwd_cfg(g, b, *pl).splits;
+    pl->fwd_splits = use_band ? band.fwd_splits : fwd_cfg(g, b, *pl).splits;
+    pl->fwd_band = use_band ? 1 : 0; pl->bwd_weight_band = 0;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
     pl->x_pm_wanted = ((want_pix_major(g, b, PM_FWD) && !pmdma_fwd(g, b)) || (pm_bwd_weight(g, b) && !pmdma_bwd_weight(g, b))) ? 1 : 0;
@@ -2812,7 +2805,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->e_pm_wanted = 0; pl->fwd_expanded = 0; pl->bwd_weight_expanded = 0; pl->e_pm_elems = 0;
     pl->row_blocks = (rowblk_fwd(g, b, *pl) ? 1 : 0) | (rowblk_bwd_data(g, b) ? 2 : 0);
     if (dw_direct(g, b)) {
-        pl->fwd_halo = pl->bwd_weight_halo = 0;                          // direct depthwise kernels: no split-K on the data path, no position-major copies
+        pl->fwd_halo = pl->bwd_weight_halo = pl->fwd_band = 0;           // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
         pl->bwd_weight_splits = dw_weight_chunks(g);
         pl->x_pm_wanted = pl->dz_pm_wanted = 0;
@@ -2863,6 +2856,12 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
     q.IPC = flat ? 1 : pl.IPC; q.KC = flat ? pl.P : pl.KC; q.Opad = pl.Opad;
     q.pair = (!flat && halo_fwd(g, b)) ? 1 : 0;
     q.cmajor = (flat && halo_bwd_weight(g, b)) ? 1 : 0;
+    q.band = 0;
+    KanBandCfg band;
+    if (!flat && pl.fwd_band && band_fwd(g, b, &band)) {
+        q.band = 1;
+        for (int i = 0; i < q.T; ++i) { q.tap_step[i] = band.tap_step[i]; q.tap_nt[i] = band.tap_nt[i]; }
+    }
     q.divT = make_fastdiv(q.T); q.divNb = make_fastdiv(q.nb); q.divIPC = make_fastdiv(q.IPC); q.divP = make_fastdiv(q.P);
     return q;
 }
@@ -3002,6 +3001,7 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan) {
 
 // Does packing this geometry need wp cleared first (pad rows)?  Cached packing cannot skip a clear conditionally.
 static bool pack_needs_clear(const KanGeom* g, const KanPlan& pl) {
+    if (pl.fwd_band) return pl.KC != pl.IPC * pl.P || g->C % pl.IPC != 0;      // pad row of an odd NG * P / channels missing from the last group
     return pl.KC != pl.IPC * pl.P || (g->C * g->kh * g->kw) % pl.IPC != 0;
 }
 
@@ -3017,9 +3017,9 @@ static int pack_weights_impl(const float* w_base, const float* w_basis, float* w
     PackGeo q = pack_geo(g, b, pl, false);
     if (fp && (pack_needs_clear(g, pl) || dw_direct(g, b))) return fail("cached packing is not offered for this geometry (kan_pack_cacheable)");
     // rows no source element maps to must be zero: pad rows of every chunk, and the missing items of the last chunk
-    if (pl.KC != pl.IPC * pl.P) {                       // (whole-buffer clear only for P that do not divide the step)
+    if (pl.KC != pl.IPC * pl.P || (pl.fwd_band && pack_needs_clear(g, pl))) {     // (whole-buffer clear only for P that do not divide the step)
         if (hipMemsetAsync(wp, 0, (size_t)pl.packed_weight_bytes, st) != hipSuccess) return fail("memset failed");
-    } else if (NI % pl.IPC != 0) {
+    } else if (!pl.fwd_band && NI % pl.IPC != 0) {
         if (G > 1) {                                        // one clear instead of G small ones
             if (hipMemsetAsync(wp, 0, (size_t)pl.packed_weight_bytes, st) != hipSuccess) return fail("memset failed");
         } else {
@@ -3124,6 +3124,12 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         }
 #undef KAN_DWF
         return launch_ok("dw_fwd");
+    }
+    if (pl.fwd_band) {
+        KanBandCfg band;
+        if (!band_fwd(g, b, &band)) return fail("internal: plan and band configuration disagree");
+        if (x != xn && b->kind != KAN_BASIS_RBF && b->kind != KAN_BASIS_POLY) return fail("this basis / activation pair runs on single-input kernels: pass xn == x");
+        return kan_band_fwd_launch(x, xn, wp, z, g, b, &band, pl.fwd_slab_elems, stream);
     }
     FwdCfg c = fwd_cfg(g, b, pl);
     if (halo_fwd(g, b)) {

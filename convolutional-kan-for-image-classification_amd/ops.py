@@ -181,6 +181,12 @@ def _tile_tag(plan) -> str:
     return "128" if plan.Opad % 128 == 0 else "64"
 
 
+def _fwd_name(plan) -> str:
+    if plan.fwd_band:                                 # band kernel tiles: 128 outputs where they fit, 192 for exactly 192, else 64 (kan_direct.hip)
+        return "k_band_fwd/o" + ("128" if plan.Opad % 128 == 0 else "192" if plan.Opad == 192 else "64")
+    return ("k_conv_fwd_halo/o" if plan.fwd_halo else "k_conv_fwd/o") + _tile_tag(plan)
+
+
 # --------------------------------------------------------------------------------------- raw stages
 def _position_major(t: torch.Tensor, ch_off: int, Cn: int) -> torch.Tensor:
     """[Cn*H*W][B] copy of channels [ch_off, ch_off+Cn) of an NCHW tensor (kan_position_major)."""
@@ -231,7 +237,7 @@ class PackedWeights:
 def _layout_key(spec: "ConvSpec", geom, plan) -> tuple:
     """What the packed layouts wp / wd depend on (kanconv.hip: wp_row, k_pack_bwd_data): the per-group channel / output counts, the
     step shape (IPC, KC), the padded dims, and whether the forward uses the halo kernels' pair order.  B, H, W enter only through those."""
-    return (spec, geom.C, geom.O, plan.P, plan.IPC, plan.KC, plan.Kpad, plan.Opad, plan.fwd_halo, plan.packed_weight_bytes, plan.bwd_data_weight_bytes)
+    return (spec, geom.C, geom.O, plan.P, plan.IPC, plan.KC, plan.Kpad, plan.Opad, plan.fwd_halo, plan.fwd_band, plan.packed_weight_bytes, plan.bwd_data_weight_bytes)
 
 
 @lru_cache(maxsize=512)
@@ -321,7 +327,7 @@ def _conv_forward(spec: ConvSpec, x, xn, w_base, w_basis, need_dgrad: bool = Tru
         # tap-major position-major kernel -- the plain copy it needs
         return z, (wd, _position_major(x, 0, Ct) if plan.x_pm_wanted else e_pm), geom, basis, plan
     x_pm = _position_major(x, 0, Ct) if (plan.x_pm_wanted and xn is None) else None
-    _launch(("k_conv_fwd_halo/o" if plan.fwd_halo else "k_conv_fwd/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
+    _launch(_fwd_name(plan), _conv_flops(geom, plan), x,
             lambda: lib.kan_conv_fwd(_ptr(x), _ptr(xn if xn is not None else x), _ptr(wp), _ptr(z), C.byref(geom), C.byref(basis),
                                      _ptr(x_pm), st), _executed_flops(geom, plan, "fwd") if (x_pm is not None or plan.row_blocks & 1) else None, _layer_tag(geom))
     return z, (wd, x_pm), geom, basis, plan

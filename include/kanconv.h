@@ -105,6 +105,8 @@ typedef struct KanPlan {
                                      kan_conv_bwd_weight_expanded / kan_conv_fwd_expanded */
     int fwd_halo, bwd_weight_halo;/* informational: the forward / weight-gradient launch of this geometry uses the halo-tile kernel
                                      (k_conv_fwd_halo / k_conv_bwd_weight_halo) -- profiling tools name their samples by it */
+    int fwd_band, bwd_weight_band;/* informational: the forward / weight-gradient launch uses the band kernels (few input channels, or an
+                                     output count that fills no 128-wide tile: k_band_fwd / k_band_bwd_weight); wp is then in band order */
     long long packed_weight_bytes;    /* G*Kpad*Opad*4    : all groups, group j at j*Kpad*Opad floats */
     long long bwd_data_weight_bytes;  /* size of the bwd-data weight layout `wd`, all groups (equal blocks) */
     long long fwd_slab_elems;         /* B*y_bstride      : stride between z slabs  */
@@ -126,8 +128,9 @@ int kan_plan(const KanGeom* geom, const KanBasis* basis, KanPlan* plan);
  *                   (3x3 / stride 1 / pad 1 layers of the default B-spline, ChebyKAN degree-3 and one-input recurrence
  *                   degree-3 specs on 32x32, 16x16, 8x8, 4x4 planes use the pair order of the halo forward kernel instead:
  *                   k = ((c/2)*T + tap)*2P + 2p + (c&1).  Poly specs with order = 0 -- basis on a second tensor xn != x,
- *                   LegendreKAN -- never do.  wp is opaque to the caller either way: it is only ever passed back to
- *                   kan_conv_fwd of the same geometry and basis.)
+ *                   LegendreKAN -- never do.  Layers served by the band kernels -- plan.fwd_band -- use
+ *                   k = ((phase, channel group, tap of the phase) step) * KC + (c % IPC) * P + p with KC = even(IPC * P).
+ *                   wp is opaque to the caller either way: it is only ever passed back to kan_conv_fwd of the same geometry and basis.)
  *   wd (bwd-data):  optional (NULL to skip), plan.bwd_data_weight_bytes (for depthwise groups -- C = 1, O <= 2, <= 9 taps,
  *                   which run on direct kernels -- it is a plain copy of wp):
  *                   wd[tap*Opad32 + o][ct*128 + cl*P + p],  c = ct*(128/P) + cl.

@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(L.KanGeom) == 16 * 4 + 16              # 16 ints (incl. groups), 2 x int64
     assert L.KanGeom.groups.offset == 60 and L.KanGeom.x_bstride.offset == 64
     assert ctypes.sizeof(L.KanBasis) == 4 * 4 + 2 * 4 + 32 * 4 + 8 and L.KanBasis.chan_table.offset == 152      # + the phase-table pointer
-    assert ctypes.sizeof(L.KanPlan) == 20 * 4 + 6 * 8           # 20 ints (incl. kernel-variant and expanded-copy flags), 6 x int64
+    assert ctypes.sizeof(L.KanPlan) == 22 * 4 + 6 * 8           # 22 ints (incl. kernel-variant and expanded-copy flags), 6 x int64
     assert ctypes.sizeof(L.KanWavGeom) == 16 * 4 + 16 and L.KanWavGeom.wavelet.offset == 60 and L.KanWavGeom.x_bstride.offset == 64
 
 

@@ -445,7 +445,9 @@ def main():
             "dtype": "f32", "data": "synthetic (randn images, randint labels; seeded random-init weights)",
             "config": {"workload": wl["desc"], "per_gpu_batch": args.batch,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                       "loss": round(float(loss.detach()), 6)},
+                       "loss": round(float(loss.detach()), 6),
+                       # cadence of the device-side weight fingerprint for layers whose host stamps are unchanged (ops._PACK_VERIFY_EVERY: 1 = every call)
+                       "pack_verify_every": __import__("convkan_amd").ops._PACK_VERIFY_EVERY},
             # ranks of the RCCL communicator the gradient all-reduce ran on (0: single process, no collective in the step)
             "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "launcher": "bench.py -> torch.distributed.run" if os.environ.get("KAN_BENCH_LAUNCHED") else ("torch.distributed.run" if world_env else "none"),

@@ -36,8 +36,12 @@ typedef struct KanBandCfg {
     int HC, span_r, OR0, OC0;     /* halo row length in cells, extra rows per image, smallest row / column offset of any tap */
     int cells;                    /* halo cells allocated per tile (largest tile) */
     int slots;                    /* expansion units per thread: ceil(NG * cells / NT) */
+    int TS;                       /* taps per barrier step of the forward (2 where one tap is under ~36 MFMAs per wave) */
     int lds_bytes, wgs_per_cu;
     int fwd_splits;               /* split-K over the (phase, group) list */
+    /* weight gradient (k_band_bwd_weight): row tiles of TR = 32 WR rows inside one (phase, channel group), all TO = 32 NI outputs per wave */
+    int bw_ok, bw_WR, bw_NI, bw_NT, bw_tiles_o, bw_row_tiles, bw_TPI, bw_ptiles, bw_cells, bw_slots, bw_lds_bytes, bw_splits;
+    unsigned short bw_ph_rt0[KAN_BAND_MAX_PHASES + 1];                      /* first row tile of each phase (NGR * ceil(nt * NPLE / TR) tiles per phase) */
     unsigned char ph_a[KAN_BAND_MAX_PHASES], ph_b[KAN_BAND_MAX_PHASES];     /* row / column phase of phase i */
     short ph_tap0[KAN_BAND_MAX_PHASES + 1];                                 /* first entry of phase i in the tap lists below */
     unsigned short tap_shift[KAN_BAND_MAX_TAPS];                            /* phase-ordered: halo shift of the tap, in cells */
@@ -48,6 +52,9 @@ typedef struct KanBandCfg {
 
 /* Fill cfg for (geom, basis); `fast` = the compile-time spec of the basis (0: none -> cfg->ok = 0).  Pure host arithmetic. */
 void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* cfg);
+/* dwp: bw_splits slabs of G * Kpad * Opad floats in band order (rows as the packed forward weights: kan_unpack_wgrad follows the plan). */
+int kan_band_bwd_weight_launch(const float* dz, const float* x, const float* xn, float* dwp, const KanGeom* g, const KanBasis* b,
+                               const KanBandCfg* cfg, long long slab_elems, void* stream);
 /* z slabs [fwd_splits][B][O_total][Ho][Wo] as kan_conv_fwd; wp in band order. */
 int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float* z, const KanGeom* g, const KanBasis* b,
                         const KanBandCfg* cfg, long long slab_elems, void* stream);

@@ -2794,9 +2794,14 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->bwd_data_slab_elems = (long long)g->B * g->x_bstride;
     pl->bwd_weight_slab_elems = (long long)G * pl->K * pl->Opad;
     pl->fwd_splits = use_band ? band.fwd_splits : fwd_cfg(g, b, *pl).splits;
-    pl->fwd_band = use_band ? 1 : 0; pl->bwd_weight_band = 0;
+    pl->fwd_band = use_band ? 1 : 0;
+    pl->bwd_weight_band = (use_band && band.bw_ok && !tuning_off("KAN_BAND_BW")) ? 1 : 0;      // same layers; its packed gradient is in the forward's band order
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
+    if (pl->bwd_weight_band) {
+        pl->bwd_weight_splits = band.bw_splits;
+        pl->bwd_weight_slab_elems = (long long)G * pl->Kpad * pl->Opad;      // rows as the packed forward weights (pad rows included)
+    }
     pl->x_pm_wanted = ((want_pix_major(g, b, PM_FWD) && !pmdma_fwd(g, b)) || (pm_bwd_weight(g, b) && !pmdma_bwd_weight(g, b))) ? 1 : 0;
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
@@ -2805,7 +2810,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->e_pm_wanted = 0; pl->fwd_expanded = 0; pl->bwd_weight_expanded = 0; pl->e_pm_elems = 0;
     pl->row_blocks = (rowblk_fwd(g, b, *pl) ? 1 : 0) | (rowblk_bwd_data(g, b) ? 2 : 0);
     if (dw_direct(g, b)) {
-        pl->fwd_halo = pl->bwd_weight_halo = pl->fwd_band = 0;           // direct depthwise kernels: no split-K on the data path, no position-major copies
+        pl->fwd_halo = pl->bwd_weight_halo = pl->fwd_band = pl->bwd_weight_band = 0;   // direct depthwise kernels: no split-K on the data path, no position-major copies
         pl->fwd_splits = pl->bwd_data_splits = 1;
         pl->bwd_weight_splits = dw_weight_chunks(g);
         pl->x_pm_wanted = pl->dz_pm_wanted = 0;
@@ -2858,8 +2863,9 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
     q.cmajor = (flat && halo_bwd_weight(g, b)) ? 1 : 0;
     q.band = 0;
     KanBandCfg band;
-    if (!flat && pl.fwd_band && band_fwd(g, b, &band)) {
-        q.band = 1;
+    if (((!flat && pl.fwd_band) || (flat && pl.bwd_weight_band)) && band_fwd(g, b, &band)) {
+        q.band = 1; q.cmajor = 0;
+        q.IPC = pl.IPC; q.KC = pl.KC; q.divIPC = make_fastdiv(q.IPC);       // (the flat gradient of a band layer has the forward's rows, pad rows included)
         for (int i = 0; i < q.T; ++i) { q.tap_step[i] = band.tap_step[i]; q.tap_nt[i] = band.tap_nt[i]; }
     }
     q.divT = make_fastdiv(q.T); q.divNb = make_fastdiv(q.nb); q.divIPC = make_fastdiv(q.IPC); q.divP = make_fastdiv(q.P);
@@ -3082,7 +3088,7 @@ int kan_unpack_wgrad(const float* dwp, float* dw_base, float* dw_basis, const Ka
     if ((hb && !dw_base) || !dw_basis || !dwp) return fail("null weight-gradient pointer");
     hipStream_t st = (hipStream_t)stream;
     const int T = g->kh * g->kw, G = ngroups(g);
-    const long long dwp_gs = (long long)pl.K * pl.Opad;
+    const long long dwp_gs = (long long)(pl.bwd_weight_band ? pl.Kpad : pl.K) * pl.Opad;
     PackGeo q = pack_geo(g, b, pl, true);
     int n_slabs = pl.bwd_weight_splits;
     if (n_slabs >= 32) {                                      // (dwp is the caller's scratch: slab 0 becomes the sum)
@@ -3332,6 +3338,12 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
         }
 #undef KAN_DWW
         return launch_ok("dw_bwd_weight");
+    }
+    if (pl.bwd_weight_band) {
+        KanBandCfg band;
+        if (!band_fwd(g, b, &band) || !band.bw_ok) return fail("internal: plan and band configuration disagree");
+        if (x != xn && b->kind != KAN_BASIS_RBF && b->kind != KAN_BASIS_POLY) return fail("this basis / activation pair runs on single-input kernels: pass xn == x");
+        return kan_band_bwd_weight_launch(dz, x, xn, dwp, g, b, &band, pl.bwd_weight_slab_elems, stream);
     }
     if (halo_bwd_weight(g, b) && x == xn) {
         const BwHaloCfg hc = bw_halo_cfg(g, pl);

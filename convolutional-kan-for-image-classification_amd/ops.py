@@ -220,15 +220,30 @@ _PACKED: "OrderedDict[tuple, PackedWeights]" = OrderedDict()
 _PACK_CACHE_MAX = int(os.environ.get("KAN_PACK_CACHE", "256"))
 _PACK_CACHE_BYTES = int(os.environ.get("KAN_PACK_CACHE_BYTES", str(16 << 30)))
 _PACK_SAMPLE = max(1, int(os.environ.get("KAN_PACK_SAMPLE", "1")))
-PACK_STATS = {"calls": 0, "forced": 0}               # host-side counters (tests, tools)
+# How often the device-side fingerprint runs for a layer whose HOST stamps (tensor identity, address, version counter) have not moved:
+# 1 = on every call (332 MB of weight reads + two early-exit pack launches per KAN-VGG11 step: 0.19 ms of 15.4); N = on every N-th call --
+# a write the version counters cannot see (`p.data.mul_()`, a raw copy into the storage) is then picked up at the next verification at the
+# latest, and at once after `weights_changed()`; 0 = never (stamps only).  Every write autograd / the optimizers can see (in-place ops,
+# load_state_dict, torch.optim, FusedAdamW) moves a stamp and re-packs on the next call whatever this is set to.
+_PACK_VERIFY_EVERY = int(os.environ.get("KAN_PACK_VERIFY_EVERY", "16"))
+_EPOCH = 0
+PACK_STATS = {"calls": 0, "forced": 0, "skipped": 0}  # host-side counters (tests, tools)
+
+
+def weights_changed() -> None:
+    """Tell the packed-weight cache that weights may have been written through a path the version counters cannot see (`.data` ops,
+    `dist.broadcast(p.data)`, raw-pointer kernels): every layer fingerprints its weights on its next call."""
+    global _EPOCH
+    _EPOCH += 1
 
 
 class PackedWeights:
-    __slots__ = ("wp", "wd", "ring", "cur", "stamps")
+    __slots__ = ("wp", "wd", "ring", "cur", "stamps", "epoch", "unverified")
 
     def __init__(self):
         self.wp = self.wd = self.ring = None
         self.cur, self.stamps = 0, None
+        self.epoch, self.unverified = -1, 0           # weights_changed() epoch of the last device-side check; calls since then
 
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in (self.wp, self.wd) if t is not None)
@@ -289,6 +304,11 @@ def _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, p
         ent.ring = torch.zeros(L.KAN_FP_WORDS, device=device, dtype=torch.int64)
     if need_dgrad and ent.wd is None:
         ent.wd = torch.empty(plan.bwd_data_weight_bytes // 4, device=device, dtype=torch.float32)
+    if not force and ent.epoch == _EPOCH and _PACK_VERIFY_EVERY != 1 and (_PACK_VERIFY_EVERY == 0 or ent.unverified + 1 < _PACK_VERIFY_EVERY):
+        ent.unverified += 1                           # host stamps unchanged and verified recently: no fingerprint, no pack launch
+        PACK_STATS["skipped"] += 1
+        return ent.wp, (ent.wd if need_dgrad else None)
+    ent.epoch, ent.unverified = _EPOCH, 0
     if force:                                         # a graph that saved the old layouts must not be differentiated any more:
         for t in (ent.wp, ent.wd):                    # autograd's saved-tensor version check raises, as it would for the weights
             if t is not None:
@@ -397,7 +417,8 @@ def _conv_backward(spec: ConvSpec, x, xn, packed, dz, need_x: bool, need_xn: boo
                     lambda: lib.kan_conv_bwd_weight_expanded(_ptr(dz_pm), _ptr(e_pm), _ptr(dwp), C.byref(geom), C.byref(basis), st),
                     _executed_flops(geom, plan, "bwd_weight"), _layer_tag(geom))
         else:
-            _launch(("k_conv_bwd_weight_halo/o" if (plan.bwd_weight_halo and xn is None) else "k_conv_bwd_weight/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
+            _launch(_fwd_name(plan).replace("fwd", "bwd_weight") if plan.bwd_weight_band else
+                    ("k_conv_bwd_weight_halo/o" if (plan.bwd_weight_halo and xn is None) else "k_conv_bwd_weight/o") + _tile_tag(plan), _conv_flops(geom, plan), x,
                     lambda: lib.kan_conv_bwd_weight(_ptr(dz), _ptr(x), _ptr(xs), _ptr(dwp), C.byref(geom), C.byref(basis), _ptr(x_pm),
                                                     _ptr(dz_pm), st),
                     _executed_flops(geom, plan, "bwd_weight") if (x_pm is not None and dz_pm is not None) else None, _layer_tag(geom))

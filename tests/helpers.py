@@ -198,21 +198,40 @@ def check_vs_oracle(layer, cfg, x, groups=1, tag=None, scale=1.0, assert_ok=True
     y.backward(go.cuda())
     torch.cuda.synchronize()
 
-    def tol(base, a32, a64):                                      # (tolerance, the fp32 oracle's own distance from fp64)
-        o = relerr(a32, a64)
-        return max(base * scale, 4.0 * o), o
-    errs = {"y": (relerr(y, y64), *tol(TOL_Y, y32, y64)), "dx": (relerr(xg.grad, dx64), *tol(TOL_DX, dx32, dx64))}
-    scal_h, scal_r, scal_64 = [], [], []
-    for name, p_ in dev.named_parameters():
-        if name not in dw32:
-            continue
-        if p_.numel() == 1:                                       # per-group PReLU slopes: judged together (one scalar each)
-            scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dw32[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
-        else:
-            errs[name] = (relerr(p_.grad, dw64[name]), *tol(TOL_DW if p_.dim() >= 3 else 2e-5, dw32[name], dw64[name]))
-    if scal_h:
-        a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
-        errs["prelus"] = (relerr(a, b64), *tol(2e-5, b, b64))
+    def judge(o32):
+        """o32 = (y, dx, {dW}) of an fp32 execution of the oracle: per tensor (HIP error, tolerance, that execution's own error), all vs fp64."""
+        def tol(base, a32, a64):
+            o = relerr(a32, a64)
+            return max(base * scale, 4.0 * o), o
+        ya, dxa, dwa = o32
+        errs = {"y": (relerr(y, y64), *tol(TOL_Y, ya, y64)), "dx": (relerr(xg.grad, dx64), *tol(TOL_DX, dxa, dx64))}
+        scal_h, scal_r, scal_64 = [], [], []
+        for name, p_ in dev.named_parameters():
+            if name not in dwa:
+                continue
+            if p_.numel() == 1:                                   # per-group PReLU slopes: judged together (one scalar each)
+                scal_h.append(p_.grad.reshape(-1).cpu()); scal_r.append(dwa[name].reshape(-1)); scal_64.append(dw64[name].reshape(-1))
+            else:
+                errs[name] = (relerr(p_.grad, dw64[name]), *tol(TOL_DW if p_.dim() >= 3 else 2e-5, dwa[name], dw64[name]))
+        if scal_h:
+            a, b, b64 = torch.cat(scal_h), torch.cat(scal_r), torch.cat(scal_64)
+            errs["prelus"] = (relerr(a, b64), *tol(2e-5, b, b64))
+        return errs
+    errs = judge((y32, dx32, dw32))
     bad = {k_: v for k_, v in errs.items() if not v[0] <= v[1]}
+    if bad and assert_ok:
+        # The reference arithmetic has more than one fp32 execution: with oneDNN off, ATen's native convolution runs the SAME ops in another
+        # summation order, and on deep or tiny-plane layers it sits 5 - 25x further from fp64 than the oneDNN path (tests/noise_probe.py;
+        # DESIGN.md section 4).  A tensor that misses 4 x the oneDNN execution's noise is judged once more against 4 x the larger of the two
+        # executions' -- the rule of the model-level tests (test_gpu_models.py: three executions of the reference), applied lazily.
+        with torch.backends.mkldnn.flags(enabled=False):
+            y32n, dx32n, dw32n, _ = oracle_run(cfg, layer.cpu(), x, go, torch.float32)
+        layer.cuda()
+        errs_n = judge((y32n, dx32n, dw32n))
+        errs = {k_: (v[0], max(v[1], errs_n[k_][1]), max(v[2], errs_n[k_][2])) for k_, v in errs.items()}
+        still = {k_: v for k_, v in errs.items() if not v[0] <= v[1]}
+        print(f"[check_vs_oracle] {tag if tag is not None else cfg}: {sorted(bad)} above 4 x the oneDNN execution's noise; judged against the larger of the "
+              f"oneDNN / native-conv executions: {'ok' if not still else still}")
+        bad = still
     assert not (bad and assert_ok), f"{tag if tag is not None else cfg}: (error, tolerance, fp32 oracle's own error) {bad}  (all: {errs})"
     return errs

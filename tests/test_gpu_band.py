@@ -47,6 +47,7 @@ def test_band_forward_vs_oracle(case, gpu_lib):
     G = kw.get("groups", 1)
     plan = ops._plan_cached(layer.conv_spec(), B, C // G, H, W, O // G, C, O)[2]
     assert plan.fwd_band == 1, f"{name}: the plan does not route this layer to the band forward kernel"
+    assert plan.bwd_weight_band == (1 if kind in ("bspline", "rbf", "cheby") and kw.get("degree", 4) == 4 else 0), name      # weight gradient in band order too
     cfg = _cfg(kind, C, O, **{"k": ks, **ckw})
     check_vs_oracle(layer, cfg, torch.randn(B, C, H, W) * 1.3, groups=G, tag=name)
 

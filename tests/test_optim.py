@@ -123,7 +123,7 @@ def test_train_model_generic_reduces_loss(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_packed_weights_follow_every_weight_update(gpu_lib):
+def test_packed_weights_follow_every_weight_update(gpu_lib, monkeypatch):
     """Single-group layers keep their packed weight layouts between calls (ops._PACKED).  Every way of changing the weights must
     be seen: in-place ops (version counter), FusedAdamW's raw-pointer kernel (it bumps the counters), and writes the counters
     cannot see -- `.data` ops, a raw copy into the storage -- which the device-side fingerprint catches.  The check is a
@@ -143,11 +143,12 @@ def test_packed_weights_follow_every_weight_update(gpu_lib):
         finally:
             ops._PACK_CACHE_MAX = keep
     ops._PACKED.clear()
-    ops.PACK_STATS.update(calls=0, forced=0)
+    ops.PACK_STATS.update(calls=0, forced=0, skipped=0)
+    monkeypatch.setattr(ops, "_PACK_VERIFY_EVERY", 1)                                # fingerprint on every call (cadence: last part of this test)
     with torch.no_grad():
         y0 = layer(x)
         y1 = layer(x)
-    assert len(ops._PACKED) == 1 and ops.PACK_STATS == {"calls": 2, "forced": 1} and torch.equal(y0, y1) and torch.equal(y0, uncached())
+    assert len(ops._PACKED) == 1 and ops.PACK_STATS == {"calls": 2, "forced": 1, "skipped": 0} and torch.equal(y0, y1) and torch.equal(y0, uncached())
     assert torch.equal(layer(x).detach(), y0)                                        # the training forward shares the layouts (+ wd: one forced pack)
     with torch.no_grad():
         layer.spline_conv[0].weight.mul_(1.5)                                        # version counter moves
@@ -176,3 +177,21 @@ def test_packed_weights_follow_every_weight_update(gpu_lib):
         layer(x)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out.backward()
+    # verification cadence (the default is every 16th call): a stamp-visible write re-packs at once; a raw write is seen at once after
+    # ops.weights_changed(), and at the 4th call at the latest with a cadence of 4; unchanged weights cost no device work in between
+    monkeypatch.setattr(ops, "_PACK_VERIFY_EVERY", 4)
+    with torch.no_grad():
+        ya = layer(x)
+        calls, skipped = ops.PACK_STATS["calls"], ops.PACK_STATS["skipped"]
+        assert torch.equal(layer(x), ya) and torch.equal(layer(x), ya)
+        assert ops.PACK_STATS["calls"] == calls and ops.PACK_STATS["skipped"] == skipped + 2
+        layer.spline_conv[0].weight.mul_(1.1)                                        # version counter: seen on the very next call
+        yb = layer(x)
+        assert not torch.equal(yb, ya) and torch.equal(yb, uncached())
+        layer.spline_conv[0].weight.data.mul_(0.9)                                   # raw write ...
+        ops.weights_changed()                                                        # ... announced
+        yc = layer(x)
+        assert not torch.equal(yc, yb) and torch.equal(yc, uncached())
+        layer.spline_conv[0].weight.data.mul_(1.2)                                   # raw write, not announced: picked up within the cadence
+        outs = [layer(x) for _ in range(4)]
+        assert torch.equal(outs[-1], uncached()) and not torch.equal(outs[-1], yc)

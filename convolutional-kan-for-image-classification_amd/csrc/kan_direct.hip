@@ -565,7 +565,8 @@ void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c) 
     c->slots = ceil_div((long long)c->NG * c->cells, c->NT);
     if (c->slots > 8) return;
     c->slots = c->slots <= 4 ? 4 : 8;
-    c->TS = (c->NPLE / 2) * c->MO * 2 < 36 ? 2 : 1;                 // taps per barrier step
+    c->TS = 1;      // taps per barrier step.  Two were measured on every target shape (3 -> 64 3x3: 0.083 -> 0.093 ms; 3 -> 64 k11 s4: 0.86 -> 0.94;
+                    // 64 -> 192 k5: 3.22 -> 3.24): the barrier is not what bounds these steps, and the doubled weight buffer costs a workgroup per CU
     const int WBUF = ceil_div(c->TS * c->NPLE * c->TO, 256) * 256;
     c->lds_bytes = (2 * WBUF + KAN_MAX_TABLE + KAN_BAND_MAX_TAPS + KAN_BAND_MAX_PHASES + c->NT + c->cells * c->NPS + c->NPS) * 4;
     if (c->lds_bytes > 80 * 1024) return;                           // two workgroups per CU at least (above 64 KB: hipFuncSetAttribute at the launch)
@@ -615,7 +616,11 @@ void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c) 
     const int need = ceil_div((long long)c->NG * c->bw_cells, c->bw_NT);
     c->bw_slots = need <= 3 ? 3 : 6;
     c->bw_lds_bytes = (2 * 16 * TO + KAN_MAX_TABLE + KAN_BAND_MAX_TAPS + KAN_BAND_MAX_PHASES + 128 + c->bw_NT + c->bw_cells * c->NPS + c->NPS) * 4;
-    const bool bw_kernel = (fast >= 1 && fast <= 4);
+    // rows of a (phase, group) fill row tiles of 32 WR rows; phases of a strided layer hold few taps each (3 -> 64 k11 s4: 144 / 96 / 64 rows),
+    // and a half-empty tile is half-wasted matrix work: below 3/4 filled the tap-major kernel keeps the layer (measured there: 1.0 vs 1.8 ms)
+    // (small launches -- under 2 GFLOP -- are latency-bound either way and keep the band kernel: one code path for a layer's forward and gradient)
+    const double dense_flops = 2.0 * g->B * g->O * g->Ho * g->Wo * (double)g->C * c->P * T * ngroups(g);
+    const bool bw_kernel = (fast >= 1 && fast <= 4) && (dense_flops < 2.0e9 || 4LL * c->n_steps * c->NPLE >= 3LL * rt * TR);
     if (bw_kernel && need <= 6 && c->bw_lds_bytes <= 80 * 1024 && rt < 65535 && (long long)c->bw_tiles_o * ngroups(g) <= 65535) {
         int wg = 160 * 1024 / c->bw_lds_bytes;
         const int by_thr = 2048 / c->bw_NT, by_reg = c->bw_NI == 6 ? (c->bw_NT <= 256 ? 3 : 1) : (c->bw_NT <= 256 ? 4 : 2);
@@ -636,7 +641,7 @@ void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c) 
 }
 
 int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float* z, const KanGeom* g, const KanBasis* b,
-                        const KanBandCfg* c, long long slab_elems, void* stream) {
+                        const KanBandCfg* c, int splits, long long slab_elems, void* stream) {
     if (!c->ok) return kan_fail_msg("internal: band forward launched without a valid configuration%s", "");
     DevGeom dg = dev_geom(g); DevBasis db = dev_basis(b);
     BandTab tb;
@@ -648,14 +653,15 @@ int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float*
         tb.ph_pack[ph] = (unsigned)c->ph_a[ph] | ((unsigned)c->ph_b[ph] << 8) | ((unsigned)c->ph_tap0[ph] << 16) |
                          ((unsigned)(c->ph_tap0[ph + 1] - c->ph_tap0[ph]) << 24);
     for (int i = 0; i < c->n_taps; ++i) tb.tap_shift[i] = c->tap_shift[i];
-    const int Opad = round_up(g->O, 64), NGI = c->n_phase * c->NGR, gps = ceil_div(NGI, c->fwd_splits);
+    if (splits < 1) return kan_fail_msg("internal: band forward needs at least one slab%s", "");
+    const int Opad = round_up(g->O, 64), NGI = c->n_phase * c->NGR, gps = ceil_div(NGI, splits);        // grid.z = the PLAN's slab count (what the caller allocated)
     if ((long long)c->tiles_o * ngroups(g) > 65535) return kan_fail_msg("groups * output tiles exceed the grid limit%s", "");
-    const dim3 grid(c->tiles_p, c->tiles_o * ngroups(g), c->fwd_splits);
+    const dim3 grid(c->tiles_p, c->tiles_o * ngroups(g), splits);
     const unsigned x_bytes = (unsigned)((long long)g->B * g->x_bstride * 4);
     hipStream_t st = (hipStream_t)stream;
 #define BAND_LAUNCH(KIND, F, NGV, WOV, MOV, SL)                                                                                         \
     do {                                                                                                                                \
-        constexpr int TSV = ((fast_planes(F) * NGV + 1) / 2) * MOV * 2 < 36 ? 2 : 1;                                                        \
+        constexpr int TSV = 1;                                                                                                              \
         static int lds_raised = 0;      /* one-time kernel attribute setup: dynamic LDS above the 64 KB default */                         \
         if (c->lds_bytes > 64 * 1024 && lds_raised < c->lds_bytes) {                                                                        \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_fwd<KIND, F, NGV, WOV, MOV, 2, SL, TSV>),                         \
@@ -698,7 +704,7 @@ int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float*
 }
 
 int kan_band_bwd_weight_launch(const float* dz, const float* x, const float* xn, float* dwp, const KanGeom* g, const KanBasis* b,
-                               const KanBandCfg* c, long long slab_elems, void* stream) {
+                               const KanBandCfg* c, int splits, long long slab_elems, void* stream) {
     if (!c->ok || !c->bw_ok) return kan_fail_msg("internal: band weight gradient launched without a valid configuration%s", "");
     DevGeom dg = dev_geom(g); DevBasis db = dev_basis(b);
     BandWTab tb;
@@ -711,8 +717,9 @@ int kan_band_bwd_weight_launch(const float* dz, const float* x, const float* xn,
                          ((unsigned)(c->ph_tap0[ph + 1] - c->ph_tap0[ph]) << 24);
     for (int ph = 0; ph <= c->n_phase; ++ph) tb.ph_rt0[ph] = c->bw_ph_rt0[ph];
     for (int i = 0; i < c->n_taps; ++i) tb.tap_shift[i] = c->tap_shift[i];
-    const int Opad = round_up(g->O, 64), Kpad = c->n_steps * c->NPLE, pps = ceil_div(c->bw_ptiles, c->bw_splits);
-    const dim3 grid(c->bw_row_tiles, c->bw_tiles_o * ngroups(g), c->bw_splits);
+    if (splits < 1) return kan_fail_msg("internal: band weight gradient needs at least one slab%s", "");
+    const int Opad = round_up(g->O, 64), Kpad = c->n_steps * c->NPLE, pps = ceil_div(c->bw_ptiles, splits);   // grid.z = the PLAN's slab count
+    const dim3 grid(c->bw_row_tiles, c->bw_tiles_o * ngroups(g), splits);
     const unsigned x_bytes = (unsigned)((long long)g->B * g->x_bstride * 4), dz_bytes = (unsigned)((long long)g->B * g->y_bstride * 4);
     hipStream_t st = (hipStream_t)stream;
 #define BANDW_LAUNCH(KIND, F, NGV, WRV, NIV, SL)                                                                                                   \

@@ -54,7 +54,7 @@ typedef struct KanBandCfg {
 void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* cfg);
 /* dwp: bw_splits slabs of G * Kpad * Opad floats in band order (rows as the packed forward weights: kan_unpack_wgrad follows the plan). */
 int kan_band_bwd_weight_launch(const float* dz, const float* x, const float* xn, float* dwp, const KanGeom* g, const KanBasis* b,
-                               const KanBandCfg* cfg, long long slab_elems, void* stream);
+                               const KanBandCfg* cfg, int splits, long long slab_elems, void* stream);
 /* z slabs [fwd_splits][B][O_total][Ho][Wo] as kan_conv_fwd; wp in band order. */
 int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float* z, const KanGeom* g, const KanBasis* b,
-                        const KanBandCfg* cfg, long long slab_elems, void* stream);
+                        const KanBandCfg* cfg, int splits, long long slab_elems, void* stream);

@@ -1734,7 +1734,13 @@ __global__ __launch_bounds__(256, 4) void k_conv_fwd_pmdma(
 
 // dW tile = 128 rows of the tap-major flat K axis (one tap: C*P % 128 == 0 is required) x 128 outputs; a step = 16 images of one
 // output position; steps whose (position, tap) pair reads padding are skipped, split ranges are cut over live steps
-// (as k_conv_bwd_weight).  No staging code at all: per step and wave 16 DMA instructions, 32 ds_read_b32, 32 MFMA.
+// (as k_conv_bwd_weight).  No staging code at all.  Round 3: both operands are [row][16 images] with the images contiguous in HBM and in LDS,
+// so they move by 16-BYTE LDS-DMA (one wave instruction = 16 rows x 64 bytes) and are read by ds_read_b128 -- a lane fetches four
+// consecutive images of its row at once.  The reduction index of an MFMA k-pair is free as long as A and B agree: lanes 0 - 31 own images
+// {0-3, 8-11} of the step, lanes 32 - 63 images {4-7, 12-15}; k-pair kk pairs image 4 (kk / 4) * 2 ... i.e. element (kk & 3) of each lane's
+// (kk >> 2)-th fetch.  The 16-byte chunks of a row are XOR-swizzled by (row >> 2) & 3 (chosen at the DMA source), which makes the b128
+// reads of 16 rows hit 64 distinct banks.  Per step and wave: 4 DMA instructions (was 16), 8 ds_read_b128 (was 32 ds_read_b32), 32 MFMA.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
     const float* __restrict__ dz_pm, const float* __restrict__ e_pm, float* __restrict__ dwp, DevGeom g, int P, FastDiv divP, int Krows, int Opad,
     int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned dz_bytes, int tiles_o) {
@@ -1754,24 +1760,26 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
     const int tap = k0 / CP, tr = tap / g.kw, tt = tap - tr * g.kw;          // the tile's tap (uniform)
     const kan_rsrc e_rs = make_rsrc(e_pm, e_bytes), dz_rs = make_rsrc(dz_pm, dz_bytes);
 
-    // ---- DMA sources: wave w copies chunks 8 w .. 8 w + 7 of each operand (64 words = 4 rows x 16 images, XOR-swizzled)
-    unsigned aoff[8], zoff[8];
+    // ---- DMA sources: wave w copies 16-row chunks m = 2 w, 2 w + 1 of each operand; lane -> (row = lane >> 2, 16-byte slot = lane & 3),
+    //      the slot holds source chunk slot ^ ((row >> 2) & 3)
+    unsigned aoff[2], zoff[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int rl = 4 * (wave * 8 + j) + (lane >> 4), q = (lane & 15) ^ ((rl >> 1) & 15);
+    for (int j = 0; j < 2; ++j) {
+        const int rl = 16 * (wave * 2 + j) + (lane >> 2), cs = (lane & 3) ^ ((rl >> 2) & 3);
         const int row = k0 + rl, rem = min(row, Krows - 1) - tap * CP, c = fastdiv(rem, divP), pp = rem - c * P;     // (computed unconditionally: no branch)
-        const unsigned va = (unsigned)(((c * HW) * P + pp) * g.B + q) * 4u, vz = (unsigned)((o_tile0 + rl) * HoWo * g.B + q) * 4u;
+        const unsigned va = (unsigned)(((c * HW) * P + pp) * g.B + cs * 4) * 4u, vz = (unsigned)((o_tile0 + rl) * HoWo * g.B + cs * 4) * 4u;
         aoff[j] = row < Krows ? va : KAN_OOB;
         zoff[j] = o_tile0 + rl < g.O ? vz : KAN_OOB;
     }
-    // ---- operand read addresses: one per k-pair (swizzle), second 32-row / 32-output block and buffer as immediates
-    unsigned aA[KPX / 2], bB[KPX / 2];
-    {
-        const int rl = w_r * 64 + (lane & 31), ol = w_c * 64 + (lane & 31);
+    // ---- operand read addresses: two 16-byte fetches per 32-row block (chunks kh2 and 2 + kh2 of the lane's row), buffer as an immediate
+    unsigned aA[2][2], bB[2][2];
 #pragma unroll
-        for (int kk = 0; kk < KPX / 2; ++kk) {
-            aA[kk] = lds_addr(sA + rl * KPX + ((2 * kk + kh2) ^ ((rl >> 1) & 15)));
-            bB[kk] = lds_addr(sZ + ol * KPX + ((2 * kk + kh2) ^ ((ol >> 1) & 15)));
+    for (int mi = 0; mi < 2; ++mi) {
+        const int rl = w_r * 64 + mi * 32 + (lane & 31), ol = w_c * 64 + mi * 32 + (lane & 31);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            aA[mi][h] = lds_addr(sA + rl * KPX + (((2 * h + kh2) ^ ((rl >> 2) & 3)) * 4));
+            bB[mi][h] = lds_addr(sZ + ol * KPX + (((2 * h + kh2) ^ ((ol >> 2) & 3)) * 4));
         }
     }
     auto issue = [&](int ch, int buf) {
@@ -1779,12 +1787,12 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
         const int ho = pos / g.Wo, wo = pos - ho * g.Wo;
         const int inpos = (ho * g.sh - g.ph + tr * g.dh) * g.W + (wo * g.sw - g.pw + tt * g.dw);     // live steps only: inside the image
         const int sa = __builtin_amdgcn_readfirstlane((inpos * P * g.B + b0) * 4), sz = __builtin_amdgcn_readfirstlane((pos * g.B + b0) * 4);
-        float* dA = sA + buf * AB + wave * (8 * 64);
-        float* dZ = sZ + buf * ZB + wave * (8 * 64);
+        float* dA = sA + buf * AB + wave * (2 * 256);
+        float* dZ = sZ + buf * ZB + wave * (2 * 256);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(e_rs, (__attribute__((address_space(3))) void*)(dA + j * 64), 4, (int)aoff[j], sa, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dZ + j * 64), 4, (int)zoff[j], sz, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(e_rs, (__attribute__((address_space(3))) void*)(dA + j * 256), 16, (int)aoff[j], sa, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dz_rs, (__attribute__((address_space(3))) void*)(dZ + j * 256), 16, (int)zoff[j], sz, 0, 0);
         }
     };
 
@@ -1821,29 +1829,30 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
     int ch = next_live(ch0);
     if (ch < ch1) issue(ch, 0);
     // the buffer index is a literal in each copy of the step, so that every LDS offset is an immediate
-#define KAN_RD(CUR, n_, kk_) asm volatile("ds_read_b32 %0, %4 offset:%6\n\tds_read_b32 %1, %4 offset:%7\n\tds_read_b32 %2, %5 offset:%6\n\tds_read_b32 %3, %5 offset:%7" \
-                : "=&v"(fa[n_][0]), "=&v"(fa[n_][1]), "=&v"(fb[n_][0]), "=&v"(fb[n_][1]) : "v"(aA[kk_]), "v"(bB[kk_]), "n"((CUR) * AB * 4), "n"((CUR) * AB * 4 + 32 * KPX * 4) : "memory")
+#define KAN_RD4(CUR, h_)                                                                                                    \
+    asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\tds_read_b128 %3, %7 offset:%8" \
+                 : "=&v"(fa[h_][0]), "=&v"(fa[h_][1]), "=&v"(fb[h_][0]), "=&v"(fb[h_][1])                                      \
+                 : "v"(aA[0][h_]), "v"(aA[1][h_]), "v"(bB[0][h_]), "v"(bB[1][h_]), "n"((CUR) * AB * 4) : "memory")
+#define KAN_PM_HALF(h_)                                                                                                     \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                          \
+        acc[0][0] = MFMA32(fa[h_][0][e], fb[h_][0][e], acc[0][0]);                                                            \
+        acc[0][1] = MFMA32(fa[h_][0][e], fb[h_][1][e], acc[0][1]);                                                            \
+        acc[1][0] = MFMA32(fa[h_][1][e], fb[h_][0][e], acc[1][0]);                                                            \
+        acc[1][1] = MFMA32(fa[h_][1][e], fb[h_][1][e], acc[1][1]);                                                            \
+    }
 #define KAN_PM_STEP(CUR)                                                                                     \
     do {                                                                                                     \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
         __syncthreads();                                                                                     \
         ch = next_live(ch + 1);                                                                              \
         if (ch < ch1) issue(ch, (CUR) ^ 1);                                                                  \
-        float fa[2][2], fb[2][2];                                                                            \
-        KAN_RD(CUR, 0, 0);                                                                                   \
-        _Pragma("unroll") for (int kk = 0; kk < KPX / 2; ++kk) {                                             \
-            const int c_ = kk & 1, n_ = c_ ^ 1;                                                              \
-            if (kk + 1 < KPX / 2) {                                                                          \
-                KAN_RD(CUR, n_, kk + 1);                                                                     \
-                LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 4);                                    \
-            } else {                                                                                         \
-                LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 0);                                    \
-            }                                                                                                \
-            acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);                                             \
-            acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);                                             \
-            acc[1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[1][0]);                                             \
-            acc[1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[1][1]);                                             \
-        }                                                                                                    \
+        f32x4 fa[2][2], fb[2][2];                                                                            \
+        KAN_RD4(CUR, 0);                                                                                     \
+        KAN_RD4(CUR, 1);                                                                                     \
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fb[0][0]), "+v"(fb[0][1]) :: "memory"); \
+        KAN_PM_HALF(0)                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fb[1][0]), "+v"(fb[1][1]) :: "memory"); \
+        KAN_PM_HALF(1)                                                                                       \
     } while (0)
     static_assert(AB == ZB, "one immediate serves both operands");
     while (ch < ch1) {                                       // (a `break` between the two copies made hipcc spill 59 VGPRs)
@@ -1851,7 +1860,8 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
         if (ch < ch1) { KAN_PM_STEP(1); }
     }
 #undef KAN_PM_STEP
-#undef KAN_RD
+#undef KAN_PM_HALF
+#undef KAN_RD4
 
     float* out = dwp + (size_t)blk.z * slab_elems;
 #pragma unroll
@@ -2795,7 +2805,9 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->bwd_weight_slab_elems = (long long)G * pl->K * pl->Opad;
     pl->fwd_splits = use_band ? band.fwd_splits : fwd_cfg(g, b, *pl).splits;
     pl->fwd_band = use_band ? 1 : 0;
-    pl->bwd_weight_band = (use_band && band.bw_ok && !tuning_off("KAN_BAND_BW")) ? 1 : 0;      // same layers; its packed gradient is in the forward's band order
+    // same layers, except the small padded planes whose weight gradient takes the position-major tap-skipping launch (its plan below sets the
+    // split count and the copies it wants); the packed gradient of a band launch is in the forward's band order
+    pl->bwd_weight_band = (use_band && band.bw_ok && !want_pix_major(g, b, PM_BWD_WEIGHT) && !tuning_off("KAN_BAND_BW")) ? 1 : 0;
     pl->bwd_data_splits = bd.splits;
     pl->bwd_weight_splits = halo_bwd_weight(g, b) ? bw_halo_cfg(g, *pl).splits : bw_cfg(g, b, *pl).splits;
     if (pl->bwd_weight_band) {
@@ -2806,7 +2818,7 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
     pl->dz_pm_wanted = (want_pix_major(g, b, PM_BWD_DATA) || pm_bwd_weight(g, b)) ? 1 : 0;
     pl->fwd_target = pl->bwd_data_target = pl->bwd_weight_target = 0;
     pl->fwd_halo = halo_fwd(g, b) ? 1 : 0;
-    pl->bwd_weight_halo = halo_bwd_weight(g, b) ? 1 : 0;
+    pl->bwd_weight_halo = (halo_bwd_weight(g, b) && !pl->bwd_weight_band) ? 1 : 0;
     pl->e_pm_wanted = 0; pl->fwd_expanded = 0; pl->bwd_weight_expanded = 0; pl->e_pm_elems = 0;
     pl->row_blocks = (rowblk_fwd(g, b, *pl) ? 1 : 0) | (rowblk_bwd_data(g, b) ? 2 : 0);
     if (dw_direct(g, b)) {
@@ -3135,7 +3147,7 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
         KanBandCfg band;
         if (!band_fwd(g, b, &band)) return fail("internal: plan and band configuration disagree");
         if (x != xn && b->kind != KAN_BASIS_RBF && b->kind != KAN_BASIS_POLY) return fail("this basis / activation pair runs on single-input kernels: pass xn == x");
-        return kan_band_fwd_launch(x, xn, wp, z, g, b, &band, pl.fwd_slab_elems, stream);
+        return kan_band_fwd_launch(x, xn, wp, z, g, b, &band, pl.fwd_splits, pl.fwd_slab_elems, stream);
     }
     FwdCfg c = fwd_cfg(g, b, pl);
     if (halo_fwd(g, b)) {
@@ -3343,7 +3355,7 @@ int kan_conv_bwd_weight(const float* dz, const float* x, const float* xn, float*
         KanBandCfg band;
         if (!band_fwd(g, b, &band) || !band.bw_ok) return fail("internal: plan and band configuration disagree");
         if (x != xn && b->kind != KAN_BASIS_RBF && b->kind != KAN_BASIS_POLY) return fail("this basis / activation pair runs on single-input kernels: pass xn == x");
-        return kan_band_bwd_weight_launch(dz, x, xn, dwp, g, b, &band, pl.bwd_weight_slab_elems, stream);
+        return kan_band_bwd_weight_launch(dz, x, xn, dwp, g, b, &band, pl.bwd_weight_splits, pl.bwd_weight_slab_elems, stream);
     }
     if (halo_bwd_weight(g, b) && x == xn) {
         const BwHaloCfg hc = bw_halo_cfg(g, pl);

@@ -47,7 +47,10 @@ def test_band_forward_vs_oracle(case, gpu_lib):
     G = kw.get("groups", 1)
     plan = ops._plan_cached(layer.conv_spec(), B, C // G, H, W, O // G, C, O)[2]
     assert plan.fwd_band == 1, f"{name}: the plan does not route this layer to the band forward kernel"
-    assert plan.bwd_weight_band == (1 if kind in ("bspline", "rbf", "cheby") and kw.get("degree", 4) == 4 else 0), name      # weight gradient in band order too
+    # the weight gradient takes the band kernel too (packed gradient in band order) where a compile-time spec exists for it, except on small
+    # padded planes with >= 16 images, which keep the position-major tap-skipping launch
+    want_bw = 1 if (kind in ("bspline", "rbf", "cheby") and kw.get("degree", 4) == 4 and name != "tiny_plane_many_images") else 0
+    assert plan.bwd_weight_band == want_bw, (name, plan.bwd_weight_band)
     cfg = _cfg(kind, C, O, **{"k": ks, **ckw})
     check_vs_oracle(layer, cfg, torch.randn(B, C, H, W) * 1.3, groups=G, tag=name)
 

@@ -6,14 +6,20 @@ so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
 with tempfile.TemporaryDirectory() as d:
     subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", so, d + "/fat.bin"], check=True)
     blob = open(d + "/fat.bin", "rb").read()
-    assert blob[:24] == b"__CLANG_OFFLOAD_BUNDLE__"
-    n, off = struct.unpack("<Q", blob[24:32])[0], 32
-    for _ in range(n):
-        o, sz, tl = struct.unpack("<QQQ", blob[off:off + 24]); off += 24
-        triple = blob[off:off + tl].decode(); off += tl
-        if "gfx950" in triple:
-            open(d + "/dev.co", "wb").write(blob[o:o + sz])
-    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", d + "/dev.co"], capture_output=True, text=True).stdout
+    notes, start, k = "", 0, 0
+    while True:                                   # one offload bundle per translation unit
+        start = blob.find(b"__CLANG_OFFLOAD_BUNDLE__", start)
+        if start < 0:
+            break
+        n, off = struct.unpack("<Q", blob[start + 24:start + 32])[0], start + 32
+        for _ in range(n):
+            o, sz, tl = struct.unpack("<QQQ", blob[off:off + 24]); off += 24
+            triple = blob[off:off + tl].decode(); off += tl
+            if "gfx950" in triple:
+                open(d + f"/dev{k}.co", "wb").write(blob[start + o:start + o + sz])
+                notes += subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", d + f"/dev{k}.co"], capture_output=True, text=True).stdout
+                k += 1
+        start += 24
     demangle = lambda s: subprocess.run(["c++filt", s], capture_output=True, text=True).stdout.strip()
 for blk in notes.split("- .agpr_count")[1:]:
     name = re.search(r"\.name:\s+(\S+)", blk).group(1)

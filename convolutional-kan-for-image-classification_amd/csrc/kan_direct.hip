@@ -201,40 +201,37 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
                 if (t < n_here) {                            // uniform
                     const unsigned sh = (unsigned)__builtin_amdgcn_readfirstlane(sShift[tap0 + j0 + t]);
                     const unsigned aw = lds_addr(sW + buf * WBUF + (t * NPLE + kh2) * TO + ao), ab0 = vb[0] + sh, ab1 = vb[1] + sh;
-                    if constexpr (MO == 2) {
-                        float fa[2][2], fb[2][2];
-                        BAND_READ4(fa[0][0], fa[0][1], fb[0][0], fb[0][1], aw, ab0, ab1, 0, 32 * 4, 0);
+                    const unsigned ab[2] = {ab0, ab1};
+                    float fa[2][MO], fb[2][2];
+                    // operand fetch in explicit ISA (immediate offsets; the reads of k-pair kk + 1 are in flight during the MFMAs of kk)
+#define BAND_RD(n_, KK)                                                                                                          \
+                    do {                                                                                                         \
+                        _Pragma("unroll") for (int mi = 0; mi < MO; ++mi)                                                        \
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fa[n_][mi]) : "v"(aw), "n"((2 * (KK)) * TO * 4 + mi * 128) : "memory"); \
+                        _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                            \
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(fb[n_][q]) : "v"(ab[q]), "n"((2 * (KK)) * 4) : "memory"); \
+                    } while (0)
+                    BAND_RD(0, 0);
 #pragma unroll
-                        for (int kk = 0; kk < NPLE / 2; ++kk) {
-                            const int c_ = kk & 1, n_ = c_ ^ 1;
-                            if (kk + 1 < NPLE / 2) {
-                                BAND_READ4(fa[n_][0], fa[n_][1], fb[n_][0], fb[n_][1], aw, ab0, ab1, (2 * (kk + 1)) * TO * 4, (2 * (kk + 1)) * TO * 4 + 128,
-                                           (2 * (kk + 1)) * 4);
-                                LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 4);
-                            } else {
-                                LDS_WAIT4(fa[c_][0], fa[c_][1], fb[c_][0], fb[c_][1], 0);
-                            }
-                            acc[0][0] = MFMA32(fa[c_][0], fb[c_][0], acc[0][0]);
-                            acc[0][1] = MFMA32(fa[c_][0], fb[c_][1], acc[0][1]);
-                            acc[MO - 1][0] = MFMA32(fa[c_][1], fb[c_][0], acc[MO - 1][0]);
-                            acc[MO - 1][1] = MFMA32(fa[c_][1], fb[c_][1], acc[MO - 1][1]);
+                    for (int kk = 0; kk < NPLE / 2; ++kk) {
+                        const int c_ = kk & 1, n_ = c_ ^ 1;
+                        if (kk + 1 < NPLE / 2) {
+                            BAND_RD(n_, kk + 1);
+                            if constexpr (MO == 1) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fa[c_][0]), "+v"(fb[c_][0]), "+v"(fb[c_][1]) :: "memory");
+                            else if constexpr (MO == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fa[c_][0]), "+v"(fa[c_][MO - 1]), "+v"(fb[c_][0]), "+v"(fb[c_][1]) :: "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(fa[c_][0]), "+v"(fa[c_][1]), "+v"(fa[c_][MO - 1]), "+v"(fb[c_][0]), "+v"(fb[c_][1]) :: "memory");
+                        } else {
+                            if constexpr (MO == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c_][0]), "+v"(fb[c_][0]), "+v"(fb[c_][1]) :: "memory");
+                            else if constexpr (MO == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c_][0]), "+v"(fa[c_][MO - 1]), "+v"(fb[c_][0]), "+v"(fb[c_][1]) :: "memory");
+                            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[c_][0]), "+v"(fa[c_][1]), "+v"(fa[c_][MO - 1]), "+v"(fb[c_][0]), "+v"(fb[c_][1]) :: "memory");
                         }
-                    } else {
-                        float fa[2], fb[2][2];
-                        BAND_READ3(fa[0], fb[0][0], fb[0][1], aw, ab0, ab1, 0, 0);
 #pragma unroll
-                        for (int kk = 0; kk < NPLE / 2; ++kk) {
-                            const int c_ = kk & 1, n_ = c_ ^ 1;
-                            if (kk + 1 < NPLE / 2) {
-                                BAND_READ3(fa[n_], fb[n_][0], fb[n_][1], aw, ab0, ab1, (2 * (kk + 1)) * TO * 4, (2 * (kk + 1)) * 4);
-                                BAND_WAIT3(fa[c_], fb[c_][0], fb[c_][1], 3);
-                            } else {
-                                BAND_WAIT3(fa[c_], fb[c_][0], fb[c_][1], 0);
-                            }
-                            acc[0][0] = MFMA32(fa[c_], fb[c_][0], acc[0][0]);
-                            acc[0][1] = MFMA32(fa[c_], fb[c_][1], acc[0][1]);
+                        for (int mi = 0; mi < MO; ++mi) {
+                            acc[mi][0] = MFMA32(fa[c_][mi], fb[c_][0], acc[mi][0]);
+                            acc[mi][1] = MFMA32(fa[c_][mi], fb[c_][1], acc[mi][1]);
                         }
                     }
+#undef BAND_RD
                 }
             }
             buf ^= 1; s += n_here;
@@ -475,14 +472,28 @@ double band_slab_cost(double slab_bytes) { const double bw = slab_bytes / 4.0e6;
 
 // Instantiated (compile-time spec, channels per group, tile) combinations.
 bool band_has_kernel(int fast, int NG, int WO, int MO, int WP) {
-    const bool tile = (WO == 2 && MO == 1 && WP == 2) || (WO == 2 && MO == 2 && WP == 2) || (WO == 3 && MO == 2 && WP == 2);
+    const bool tile = WO == 2 && ((WP == 2 && MO >= 1 && MO <= 3) || (WP == 4 && MO == 1));
     if (!tile || NG < 1 || NG > 3) return false;
     return fast == 1 || fast == 2 || fast == 3 || fast == 4 || fast == 5 || fast == 6;
 }
 
 }  // namespace
 
+static void band_cfg_pass(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c, bool wide_pixels);
+
+// The halo tile is what a pixel tile costs: its cells are expanded once per (phase, channel group), whatever the tile's pixel count.  64-output
+// layers whose halo is large next to the tile (strided or wide kernels: 3 -> 64 k11 s4 expands 580 cells per 128 pixels -- 3.2 vector
+// instructions per MFMA, measured) take 256-pixel tiles on eight waves where that brings the cells per pixel down by a quarter or more.
 void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c) {
+    band_cfg_pass(g, b, fast, c, false);
+    if (round_up(g->O, 64) % 128 != 0 && round_up(g->O, 64) != 192) {          // 64-output tiles only
+        KanBandCfg w;
+        band_cfg_pass(g, b, fast, &w, true);
+        if (w.ok && (!c->ok || 4LL * w.cells * c->TP <= 3LL * c->cells * w.TP)) *c = w;
+    }
+}
+
+static void band_cfg_pass(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c, bool wide_pixels) {
     memset(c, 0, sizeof(*c));
     if (!fast) return;
     const int T = g->kh * g->kw;
@@ -494,10 +505,12 @@ void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c) 
     c->NPLE = NPL + (NPL & 1); c->NPS = c->NPLE + 1;
     c->NGR = ceil_div(g->C, c->NG);
     const int Opad = round_up(g->O, 64);
-    c->WP = 2;                                                      // 128-pixel tiles, 4 or 6 waves
-    if (Opad % 128 == 0) { c->WO = 2; c->MO = 2; }                   // 128 outputs: wave tile 64 x 64
-    else if (Opad == 192) { c->WO = 3; c->MO = 2; }                  // 192 outputs on six waves
-    else { c->WO = 2; c->MO = 1; }                                   // 64 outputs: wave tile 32 x 64
+    c->WO = 2; c->WP = 2;                                           // four waves: 2 along the outputs x 2 along the 128 pixels
+    if (Opad % 128 == 0) c->MO = 2;                                  // 128 outputs: wave tile 64 x 64
+    else if (Opad == 192) c->MO = 3;                                 // 192 outputs: wave tile 96 x 64 (six waves of 64 x 64 left two SIMDs with twice the
+                                                                     // work of the others and the rest parked at the step barrier: 43 % of wave time, PMC)
+    else c->MO = 1;                                                  // 64 outputs: wave tile 32 x 64
+    if (wide_pixels) c->WP = 4;                                      // second pass (below): 256-pixel tiles, eight waves
     if (!band_has_kernel(fast, c->NG, c->WO, c->MO, c->WP)) return;
     c->TO = c->WO * c->MO * 32; c->TP = c->WP * 64; c->NT = c->WO * c->WP * 64;
     c->tiles_o = Opad / c->TO;
@@ -571,7 +584,7 @@ void kan_band_cfg(const KanGeom* g, const KanBasis* b, int fast, KanBandCfg* c) 
     c->lds_bytes = (2 * WBUF + KAN_MAX_TABLE + KAN_BAND_MAX_TAPS + KAN_BAND_MAX_PHASES + c->NT + c->cells * c->NPS + c->NPS) * 4;
     if (c->lds_bytes > 80 * 1024) return;                           // two workgroups per CU at least (above 64 KB: hipFuncSetAttribute at the launch)
     int wgs = 160 * 1024 / c->lds_bytes;
-    const int by_threads = 2048 / c->NT, by_regs = c->NT <= 256 ? 3 : 2;
+    const int by_threads = 2048 / c->NT, by_regs = c->MO == 3 ? 3 : c->NT <= 256 ? 4 : 2;
     wgs = wgs < by_threads ? wgs : by_threads; wgs = wgs < by_regs ? wgs : by_regs;
     c->wgs_per_cu = wgs < 1 ? 1 : wgs;
     // ---- split-K over the (phase, group) list: the round model of pick_splits (kanconv.hip)
@@ -659,24 +672,24 @@ int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float*
     const dim3 grid(c->tiles_p, c->tiles_o * ngroups(g), splits);
     const unsigned x_bytes = (unsigned)((long long)g->B * g->x_bstride * 4);
     hipStream_t st = (hipStream_t)stream;
-#define BAND_LAUNCH(KIND, F, NGV, WOV, MOV, SL)                                                                                         \
+#define BAND_LAUNCH(KIND, F, NGV, MOV, WPV, SL)                                                                                         \
     do {                                                                                                                                \
-        constexpr int TSV = 1;                                                                                                              \
         static int lds_raised = 0;      /* one-time kernel attribute setup: dynamic LDS above the 64 KB default */                         \
         if (c->lds_bytes > 64 * 1024 && lds_raised < c->lds_bytes) {                                                                        \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_fwd<KIND, F, NGV, WOV, MOV, 2, SL, TSV>),                         \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_band_fwd<KIND, F, NGV, 2, MOV, WPV, SL, 1>),                           \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)                                   \
                 return kan_fail_msg("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed%s", "");                                        \
             lds_raised = 80 * 1024;                                                                                                         \
         }                                                                                                                                   \
-        hipLaunchKernelGGL((k_band_fwd<KIND, F, NGV, WOV, MOV, 2, SL, TSV>), grid, dim3(WOV * 2 * 64), (size_t)c->lds_bytes, st, x, xn, wp, z, \
+        hipLaunchKernelGGL((k_band_fwd<KIND, F, NGV, 2, MOV, WPV, SL, 1>), grid, dim3(2 * WPV * 64), (size_t)c->lds_bytes, st, x, xn, wp, z, \
                            dg, db, tb, Opad, gps, slab_elems, x_bytes, c->tiles_o);                                                         \
     } while (0)
-#define BAND_SLOTS(KIND, F, NGV, WOV, MOV) do { if (c->slots <= 4) BAND_LAUNCH(KIND, F, NGV, WOV, MOV, 4); else BAND_LAUNCH(KIND, F, NGV, WOV, MOV, 8); } while (0)
+#define BAND_SLOTS(KIND, F, NGV, MOV, WPV) do { if (c->slots <= 4) BAND_LAUNCH(KIND, F, NGV, MOV, WPV, 4); else BAND_LAUNCH(KIND, F, NGV, MOV, WPV, 8); } while (0)
 #define BAND_TILE(KIND, F, NGV)                                                                \
     do {                                                                                       \
-        if (c->WO == 2 && c->MO == 1) BAND_SLOTS(KIND, F, NGV, 2, 1);                           \
-        else if (c->WO == 2) BAND_SLOTS(KIND, F, NGV, 2, 2);                                    \
+        if (c->MO == 1 && c->WP == 4) BAND_SLOTS(KIND, F, NGV, 1, 4);                           \
+        else if (c->MO == 1) BAND_SLOTS(KIND, F, NGV, 1, 2);                                    \
+        else if (c->MO == 2) BAND_SLOTS(KIND, F, NGV, 2, 2);                                    \
         else BAND_SLOTS(KIND, F, NGV, 3, 2);                                                    \
     } while (0)
 #define BAND_NG(KIND, F)                                                                       \

@@ -260,6 +260,34 @@ class KANConvNDLayer(_HipLayer):
     def conv_spec(self) -> ops.ConvSpec:
         return self._spec(**self._basis_kw())
 
+    def _plane_windows(self):
+        """The library holds at most KAN_MAX_PLANES = 16 planes per channel in one launch; the reference takes any grid_size
+        (kan_layers.py:117-131).  B-spline basis j is a function of knots j .. j + order + 1 alone, so bases [j0, j1) of this layer ARE the
+        bases of a B-spline layer built on knots[j0 : j1 + order + 1] -- and the conv stage is linear in the planes.  A layer of more than
+        16 planes therefore runs one launch set per window of <= 16 planes (the first carries the base branch) and sums the results:
+        [(spec, j0, j1, with_base), ...]."""
+        n, S, knots = self.grid_size + self.spline_order, self.spline_order, [float(v) for v in self.grid.tolist()]
+        out, j0, first = [], 0, True
+        while j0 < n:
+            has_base = first and self._act_code != L.ACT_NONE
+            j1 = min(n, j0 + L.KAN_MAX_PLANES - (1 if has_base else 0))
+            out.append((self._spec(kind=L.BASIS_BSPLINE, n_basis=j1 - j0, order=S, act=self._act_code if has_base else L.ACT_NONE, p0=0.0, p1=0.0,
+                                   table=tuple(knots[j0:j1 + S + 1])), j0, j1, has_base))
+            j0, first = j1, False
+        return out
+
+    def _windowed_stage(self, xa, xb, wb, ws):
+        """Conv stage of a layer with more than 16 planes per channel: sum over plane windows (differentiable: autograd routes the
+        gradient of each weight slice back into spline_conv[g].weight)."""
+        n = self.grid_size + self.spline_order
+        z = None
+        for spec, j0, j1, has_base in self._plane_windows():
+            wsl = [w.reshape(w.shape[0], w.shape[1] // n, n, *w.shape[2:])[:, :, j0:j1].reshape(w.shape[0], -1, *w.shape[2:]) for w in ws]
+            part = ops.kan_conv(spec, xa if has_base else (xb if xb is not None else xa), None if (not has_base or xb is None) else xb,
+                                wb if has_base else [], wsl)
+            z = part if z is None else z + part
+        return z
+
     def _forward3d(self, x):
         xa, xb = self._base_input(x)
         z = conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, xa, xb,
@@ -279,6 +307,11 @@ class KANConvNDLayer(_HipLayer):
         wb, ws = self._w(self.base_conv), self._w(self.spline_conv)
         prelus = [m.weight for m in self.prelus]
         xa, xb = self._base_input(x)
+        if spec.n_basis + int(spec.has_base) > L.KAN_MAX_PLANES:             # more planes than one launch holds: plane windows, un-fused tail
+            y = self._norm_prelu(self._windowed_stage(xa, xb, wb, ws))
+            if self.dropout is not None:
+                y = self.dropout(y)
+            return F.max_pool2d(y, 2, 2) if pool else y
         if xb is None and _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
             if pool and self.ndim == 2 and self.dropout is None:

@@ -111,6 +111,10 @@ CASES = [
     C("cheby", "x3", 2, 3, 4, 8, 8, xs=3.0),
     C("cheby", "x12", 2, 3, 4, 8, 8, xs=12.0),                      # tanh saturation / clamp-active region
     C("cheby", "alex_l3", 1, 20, 32, 13, 13, degree=4, norm_kwargs={"affine": True}),
+    # more than KAN_MAX_PLANES = 16 planes per channel (kan_layers.py:117-131 takes any grid_size): the layer runs the conv stage once per
+    # WINDOW of <= 16 planes (B-spline j depends on knots j .. j + order + 1 only, so a window is a B-spline layer on a slice of the knots)
+    C("bspline", "grid16", 2, 3, 4, 8, 8, grid_size=16, act="silu"),
+    C("bspline", "grid40_order2_s2g2", 2, 4, 6, 9, 7, grid_size=40, spline_order=2, s=2, groups=2, grid_range=[-2.0, 2.0], xs=2.0, norm_kwargs={"affine": True}),
 ]
 
 
@@ -809,6 +813,13 @@ def dropin_check():
 
 
 def main():
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]       # --case=bspline_grid16: just these base-list fixtures (seed = list index)
+    if only:
+        for i, c in enumerate(CASES):
+            if f"{c['kind']}_{c['name']}" in only:
+                worst, sz = run_case(i, c)
+                print(f"{c['kind']:8s} {c['name']:12s} oracle-vs-ref max rel err {worst:.2e}  {sz / 1024:.0f} KiB")
+        return
     if "--dropin-only" in sys.argv:                 # the reference's unchanged model files on this repo's factory
         return dropin_check()
     if "--mlp-only" in sys.argv:                    # regenerate just the MLP KANLayer fixtures

@@ -368,3 +368,19 @@ def test_reference_model_files_build_unchanged_on_this_factory():
         m = mk()
         assert [(k, list(v.shape)) for k, v in m.state_dict().items()] == [(k, list(s)) for k, s in r["state_dict"]], name
         assert sum(p.numel() for p in m.parameters()) == r["parameters"] and getattr(m, "name", type(m).__name__) == r["class_name"], name
+
+
+def test_plane_windows_cover_every_basis_of_a_wide_grid():
+    """grid_size + spline_order + 1 > KAN_MAX_PLANES = 16 (the reference takes any grid_size, kan_layers.py:117-131): the layer cuts its bases
+    into windows of <= 16 planes, each a B-spline spec on the matching slice of the fp32 knots (basis j lives on knots j .. j + order + 1)."""
+    for gs, order, act in [(16, 3, nn.SiLU), (40, 2, nn.GELU), (13, 3, None), (12, 3, nn.SiLU), (100, 1, nn.SiLU)]:
+        lay = K.KANConv2DLayer(3, 4, 3, padding=1, grid_size=gs, spline_order=order, base_activation=act)
+        n, knots = gs + order, [float(v) for v in lay.grid.tolist()]
+        wins = lay._plane_windows()
+        assert wins[0][1] == 0 and wins[-1][2] == n and all(a[2] == b[1] for a, b in zip(wins, wins[1:]))      # contiguous cover of [0, n)
+        for i, (spec, j0, j1, has_base) in enumerate(wins):
+            assert has_base == (i == 0) and spec.n_basis == j1 - j0 and spec.n_basis + int(spec.has_base) <= L.KAN_MAX_PLANES
+            assert spec.table == tuple(knots[j0:j1 + order + 1]) and spec.order == order
+            assert spec.has_base == has_base                         # (base_activation=None is Identity: still a base branch, kan_layers.py:132)
+        if n + 1 <= L.KAN_MAX_PLANES:
+            assert len(wins) == 1

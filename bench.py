@@ -52,7 +52,8 @@ WORKLOADS = {
                                                              "3x224x224, fwd+CE loss+bwd (BASELINE.json configs[4]); FLOPs = conv stages only"),
     "fastkan_layer": dict(metric="images/sec fwd+bwd single FastKANConv2DLayer 3->64 k3 on 3x32x32 bs=256/GPU", shape=(3, 32, 32), batch=256,
                           gflop_per_image=3 * 2.0 * 64 * 30 * 30 * 3 * 9 * 9 / 1e9,
-                          desc="one FastKANConv2DLayer(3, 64, 3) (RBF grid 8, SiLU, input InstanceNorm2d), fwd + sum-loss + bwd (BASELINE.json configs[1])"),
+                          desc="one FastKANConv2DLayer(3, 64, 3) (RBF grid 8, SiLU, input InstanceNorm2d) on 256x3x32x32, fwd + bwd from an upstream gradient randn_like(y) "
+                               "(BASELINE.json configs[1]; SURVEY.md 8(d))"),
 }
 
 
@@ -67,18 +68,28 @@ def build_model(device, workload="kan_vgg11"):
         return alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4).to(device).train()
     import convkan_amd
 
-    class OneLayer(torch.nn.Module):                       # logits = spatial mean of the layer output (10 of its 64 channels)
+    class OneLayer(torch.nn.Module):                       # y = layer(x), backward from a fixed upstream gradient randn_like(y)
         def __init__(self):
             super().__init__()
             self.layer = convkan_amd.FastKANConv2DLayer(3, 64, 3)
+            self.upstream = None
 
         def forward(self, x):
-            return self.layer(x).mean(dim=(2, 3))[:, :10]
+            return self.layer(x)
+
+        def step(self, x):
+            y = self.layer(x)
+            if self.upstream is None or self.upstream.shape != y.shape:
+                self.upstream = torch.randn(y.shape, device=y.device, generator=torch.Generator(device=y.device).manual_seed(2))
+            y.backward(self.upstream)
+            return y.detach().flatten()[0]
     return OneLayer().to(device).train()
 
 
 def one_step(model, x, t, reducer=None):
     model.zero_grad(set_to_none=True)
+    if hasattr(model, "step"):                             # single-layer workload: its own step (no loss head)
+        return model.step(x)
     loss = F.cross_entropy(model(x), t)
     loss.backward()
     if reducer is not None:

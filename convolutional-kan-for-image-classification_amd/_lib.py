@@ -10,7 +10,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkanconv.so")
+# KANCONV_LIB: load a measurement variant of the library instead (tools/ab_env.py: a -DKAN_TUNING_KNOBS build next to the shipped one); unset in any normal use
+LIB_PATH = os.environ.get("KANCONV_LIB") or os.path.join(_HERE, "libkanconv.so")
 
 KAN_MAX_PLANES = 16
 KAN_MAX_TABLE = 32

@@ -1740,10 +1740,18 @@ __global__ __launch_bounds__(256, 4) void k_conv_fwd_pmdma(
 // {0-3, 8-11} of the step, lanes 32 - 63 images {4-7, 12-15}; k-pair kk pairs image 4 (kk / 4) * 2 ... i.e. element (kk & 3) of each lane's
 // (kk >> 2)-th fetch.  The 16-byte chunks of a row are XOR-swizzled by (row >> 2) & 3 (chosen at the DMA source), which makes the b128
 // reads of 16 rows hit 64 distinct banks.  Per step and wave: 4 DMA instructions (was 16), 8 ds_read_b128 (was 32 ds_read_b32), 32 MFMA.
+// Dispatch order (round 3).  A tile's live work depends on its tap (9 / 12 / 16 live positions on a 4x4 plane) and every tile is cut into
+// ceil(live / target) splits, so the launch is ~2 000 workgroups of 96 - 144 steps over 1 024 slots: dispatched tap by tap, the second wave of
+// workgroups started behind whatever the first happened to hold and the launch took ~300 step times for 225 steps of work per slot.  Workgroups are
+// dealt in order of their linear id as slots free up, so the host sorts the (tap, split) classes by DECREASING step count (longest first: greedy
+// list scheduling) and the kernel looks its (tile, split) up from a flat id; empty splits (they still write their zero slab) come last.
+constexpr int PM_ORDER_MAX = 72;
+struct PmOrder { int n, tiles_r_per_tap; unsigned char tap[PM_ORDER_MAX], z[PM_ORDER_MAX]; int first[PM_ORDER_MAX + 1]; };   // n == 0: plain 3-D grid
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
     const float* __restrict__ dz_pm, const float* __restrict__ e_pm, float* __restrict__ dwp, DevGeom g, int P, FastDiv divP, int Krows, int Opad,
-    int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned dz_bytes, int tiles_o) {
+    int n_chunks, int chunks_per_split, long long slab_elems, unsigned e_bytes, unsigned dz_bytes, int tiles_o, int max_splits, PmOrder ord) {
     constexpr int TR = 128, TO = 128, KPX = 16, ZB = KPX * TO, AB = KPX * TR;
     __shared__ __attribute__((aligned(16))) float sA[2 * AB];
     __shared__ __attribute__((aligned(16))) float sZ[2 * ZB];
@@ -1751,7 +1759,14 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w_r = wave >> 1, w_c = wave & 1, kh2 = lane >> 5;
     const int HoWo = g.Ho * g.Wo, HW = g.H * g.W, CP = g.C * P;
-    const BlockId blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    BlockId blk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    if (ord.n) {                                              // flat grid, longest (tap, split) class first
+        const int lin = (int)blockIdx.x;
+        int e = 0;
+        while (e + 1 < ord.n && lin >= ord.first[e + 1]) ++e;
+        const int rel = lin - ord.first[e], y = rel / ord.tiles_r_per_tap;
+        blk.x = (int)ord.tap[e] * ord.tiles_r_per_tap + (rel - y * ord.tiles_r_per_tap); blk.y = y; blk.z = (int)ord.z[e];
+    }
     const int grp = blk.y / tiles_o;
     const int k0 = blk.x * TR, o_tile0 = (blk.y - grp * tiles_o) * TO;
     e_pm += (size_t)grp * g.C * HW * P * g.B;
@@ -1811,7 +1826,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
     int ch0, ch1;
     {
         const int L = live_step_count(hwmask, HoWo, n_chunks, seg);
-        const int S = min((int)gridDim.z, max(1, (L + chunks_per_split - 1) / chunks_per_split));
+        const int S = min(max_splits, max(1, (L + chunks_per_split - 1) / chunks_per_split));
         if (blk.z >= S) { ch0 = ch1 = n_chunks; }
         else {
             ch0 = blk.z == 0 ? 0 : live_step_pos(hwmask, HoWo, n_chunks, (int)((long long)L * blk.z / S), seg);
@@ -2577,7 +2592,9 @@ bool band_fwd(const KanGeom* g, const KanBasis* b, KanBandCfg* out = nullptr) {
     if (tuning_off("KAN_BAND") || !(f >= 1 && f <= 6)) return false;
     if (b->kind == KAN_BASIS_POLY && b->order == 0) return false;            // (LegendreKAN: second input tensor; keep it on the tap-major kernel for now)
     if (dw_direct(g, b) || want_pix_major(g, b, PM_FWD) || halo_fwd(g, b)) return false;
-    if (!(g->C <= 3 || round_up(g->O, 64) % 128 != 0)) return false;
+    // ... and (round 3, measured on the 13x13 ChebyKAN-AlexNet layers) every other layer of >= 4 taps that the halo kernel's plane list does not cover:
+    // one expansion per channel group instead of one per tap
+    if (!(g->C <= 3 || round_up(g->O, 64) % 128 != 0 || (g->kh * g->kw >= 4 && g->C % 2 == 0 && !tuning_off("KAN_BAND_WIDE")))) return false;
     KanBandCfg c;
     kan_band_cfg(g, b, f, &c);
     if (out) *out = c;
@@ -3484,9 +3501,36 @@ int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* d
     dg.pix_major = 1;
     if ((long long)c.tiles_o * ngroups(g) > 65535) return fail("groups * output tiles exceed the grid limit");
     dim3 grid(c.tiles_r, c.tiles_o * ngroups(g), pl.bwd_weight_splits);
+    // longest-first dispatch order over the (tap, split) classes (PmOrder): live steps of a tap = live positions x 16-image chunks, cut into
+    // min(splits, ceil(live / target)) ranges exactly as the kernel cuts them
+    PmOrder ord; ord.n = 0;
+    const int T = g->kh * g->kw, S = pl.bwd_weight_splits, trpt = (g->C * pl.P) / 128;
+    if (!tuning_off("KAN_PM_LPT") && T * S <= PM_ORDER_MAX && T <= 255 && S <= 255 && trpt * T == c.tiles_r) {
+        int steps[PM_ORDER_MAX], idx[PM_ORDER_MAX], n = 0;
+        unsigned char tp[PM_ORDER_MAX], zz[PM_ORDER_MAX];
+        const int per_pos = ceil_div(g->B, 16), tgt = pl.bwd_weight_target > 0 ? pl.bwd_weight_target : 1;
+        for (int tap = 0; tap < T; ++tap) {
+            const int L = live_positions_for_tap(g, tap) * per_pos;
+            int St = ceil_div(L, tgt); St = St < 1 ? 1 : St; St = St > S ? S : St;
+            for (int z = 0; z < S; ++z) {
+                steps[n] = z < St ? (int)((long long)L * (z + 1) / St - (long long)L * z / St) : 0;
+                tp[n] = (unsigned char)tap; zz[n] = (unsigned char)z; idx[n] = n; ++n;
+            }
+        }
+        for (int i = 1; i < n; ++i) {                            // insertion sort by decreasing steps (stable)
+            const int v = idx[i]; int j = i;
+            while (j > 0 && steps[idx[j - 1]] < steps[v]) { idx[j] = idx[j - 1]; --j; }
+            idx[j] = v;
+        }
+        const int per_entry = trpt * c.tiles_o * ngroups(g);
+        ord.n = n; ord.tiles_r_per_tap = trpt;
+        for (int i = 0; i < n; ++i) { ord.tap[i] = tp[idx[i]]; ord.z[i] = zz[idx[i]]; ord.first[i] = i * per_entry; }
+        ord.first[n] = n * per_entry;
+        grid = dim3((unsigned)(n * per_entry), 1, 1);
+    }
     hipLaunchKernelGGL(k_conv_bwd_weight_pmdma, grid, dim3(256), 0, (hipStream_t)stream, dz_pm, e_pm, dwp, dg, pl.P, make_fastdiv(pl.P), pl.K, pl.Opad, c.chunks,
                        pl.bwd_weight_target, pl.bwd_weight_slab_elems, (unsigned)(((long long)pl.e_pm_elems - 256) * 4),
-                       (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o);
+                       (unsigned)((long long)g->B * g->y_bstride * 4), c.tiles_o, pl.bwd_weight_splits, ord);
     return launch_ok("conv_bwd_weight_expanded");
 }
 

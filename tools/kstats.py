@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print a rocprofv3 --stats kernel_stats.csv as ms per step.  usage: kstats.py <dir> <steps_profiled>"""
 import csv, glob, re, sys
-rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + "/*/*kernel_stats.csv")[0])))
+rows = list(csv.DictReader(open(sorted(glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True))[0])))
 n = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 tot = 0.0
 for r in rows:

@@ -28,8 +28,8 @@ namespace {
 
 // Device view of KanBandCfg (by-value kernel argument).
 struct BandTab {
-    int n_phase, NGR, HC, span_r, OR0, OC0, cells, n_steps;
-    FastDiv divHC, divBlk, divCells, divNGR;                   // by HC, by Ho + span_r, by cells, by NGR
+    int n_phase, NGR, HC, span_r, OR0, OC0, cells, n_steps, nslots;   // nslots: expansion units per thread actually needed (<= SLOTS)
+    FastDiv divHC, divBlk, divCells, divNGR, divHoWo, divWo;   // by HC, by Ho + span_r, by cells, by NGR, by Ho * Wo, by Wo
     unsigned ph_pack[KAN_BAND_MAX_PHASES];                     // a | b << 8 | first tap << 16 | taps << 24
     unsigned short tap_shift[KAN_BAND_MAX_TAPS];               // phase-ordered, in cells
 };
@@ -72,12 +72,17 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     if (tid < KAN_BAND_MAX_TAPS) sShift[tid] = (int)tb.tap_shift[tid] * (NPS * 4);
     if (tid < KAN_BAND_MAX_PHASES) sPh[tid] = tb.ph_pack[tid];
-    for (int i = tid; i < tb.cells * NPS + NPS; i += NT) sH[i] = 0.f;      // pad rows, pad words, out-of-image cells: zero for good
+    // every plane word of every cell is (re)written by each group's expansion, zeros included; what no expansion writes is the zero row
+    // that pads an odd plane count: it is multiplied by zero weights, but must be finite.  (Round 3: the first version zero-filled the
+    // whole tile -- 23 LDS stores per thread and tile -- and spent ~60 % of its 3.5 vector instructions per MFMA on runtime integer divisions,
+    // unit decode of unused slots and that fill: PMC on 3 -> 64 @32x32.)
+    if (NPL & 1)
+        for (int i = tid; i < tb.cells; i += NT) sH[i * NPS + NPL] = 0.f;
 
     // ---- the tile: TP consecutive output pixels from px_tile0, in (image, row, column) order (band_emul.py: tile_layout)
     const int p_last = min(px_tile0 + TP, Mtot) - 1;
-    const int b0 = px_tile0 / HoWo, ho0 = (px_tile0 - b0 * HoWo) / g.Wo;
-    const int b1 = p_last / HoWo, ho1 = (p_last - b1 * HoWo) / g.Wo;
+    const int b0 = fastdiv(px_tile0, tb.divHoWo), ho0 = fastdiv(px_tile0 - b0 * HoWo, tb.divWo);
+    const int b1 = fastdiv(p_last, tb.divHoWo), ho1 = fastdiv(p_last - b1 * HoWo, tb.divWo);
     const int n0 = (b0 == b1 ? ho1 : g.Ho - 1) - ho0 + 1;                   // output rows of the first image
     const int blk0 = n0 + tb.span_r, blkN = g.Ho + tb.span_r;               // virtual rows of image 0 / of every later image
 
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
         const int px = px_tile0 + w_p * 64 + q * 32 + (lane & 31);
         int cell = 0;
         if (px < Mtot) {
-            const int b = px / HoWo, r = px - b * HoWo, ho = r / g.Wo, wo = r - ho * g.Wo, k = b - b0;
+            const int b = fastdiv(px, tb.divHoWo), r = px - b * HoWo, ho = fastdiv(r, tb.divWo), wo = r - ho * g.Wo, k = b - b0;
             const int v = k == 0 ? ho - ho0 : blk0 + (k - 1) * blkN + ho;
             cell = v * tb.HC + wo;
         }
@@ -97,9 +102,10 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
     }
 
     // ---- expansion units of this thread (fixed per tile): unit = channel-of-group * cells + cell -> (image, sub-row i, sub-column j)
-    int u_ij[SLOTS], u_base[SLOTS], u_dst[SLOTS]; unsigned u_ok = 0;       // u_ij = i (low 16, signed) | j << 16;  u_dst = LDS word | ch << 24
+    int u_ij[SLOTS], u_base[SLOTS], u_dst[SLOTS]; unsigned u_ok = 0, u_img = 0;   // u_ij = i (low 16, signed) | j << 16;  u_dst = LDS word | ch << 24
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
+        if (k >= tb.nslots) continue;                        // uniform: slots this geometry does not need cost nothing
         const int u = tid + k * NT;
         const int ch = fastdiv(u, tb.divCells), cell = u - ch * tb.cells;
         const int v = fastdiv(cell, tb.divHC), jj = cell - v * tb.HC;
@@ -109,7 +115,8 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
         u_ij[k] = (i & 0xffff) | (j << 16);
         u_base[k] = img * (int)g.xbs + ch * HW;
         u_dst[k] = (cell * NPS + ch * P) | (ch << 24);
-        u_ok |= ((ch < NG && img < g.B) ? 1u : 0u) << k;
+        u_ok |= ((ch < NG) ? 1u : 0u) << k;                  // the unit exists: its planes are written on every expansion (zeros where there is no input)
+        u_img |= ((img < g.B) ? 1u : 0u) << k;
     }
     const bool same_in = (KIND != KAN_BASIS_RBF && KIND != KAN_BASIS_POLY) || (x == xn);
     const kan_rsrc x_rs = make_rsrc(x, x_bytes), xn_rs = make_rsrc(same_in ? x : xn, x_bytes);
@@ -121,9 +128,10 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
         inb_mask = 0; s_cbase = cbase;
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
+            if (k >= tb.nslots) continue;
             const int i = (int)(short)(u_ij[k] & 0xffff), j = u_ij[k] >> 16, ch = u_dst[k] >> 24;
             const int row = g.sh * i + pa, col = g.sw * j + pb;
-            const bool inb = ((u_ok >> k) & 1u) && cbase + ch < g.C && (unsigned)row < (unsigned)g.H && (unsigned)col < (unsigned)g.W;
+            const bool inb = ((u_ok & u_img) >> k) & 1u && cbase + ch < g.C && (unsigned)row < (unsigned)g.H && (unsigned)col < (unsigned)g.W;
             const unsigned off = inb ? (unsigned)(u_base[k] + cbase * HW + row * g.W + col) * 4u : KAN_OOB;
             xa[k] = buf_load(x_rs, off);
             xb[k] = same_in ? xa[k] : buf_load(xn_rs, off);
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
     auto expand = [&]() {                                    // write the P planes of every unit (zeros outside the image / past the last channel)
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k)
-            if ((u_ok >> k) & 1u)
+            if (k < tb.nslots && ((u_ok >> k) & 1u))
                 stage_unit<KIND, FAST>(bs, sTab, (inb_mask >> k) & 1u, xa[k], xb[k], sH + (u_dst[k] & 0xffffff), 1, sDump + tid, s_cbase + (u_dst[k] >> 24));
     };
 
@@ -244,7 +252,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
     for (int ni = 0; ni < 2; ++ni) {
         const int px = px_tile0 + w_p * 64 + ni * 32 + (lane & 31);
         if (px >= Mtot) continue;
-        const int b = px / HoWo, hw = px - b * HoWo;
+        const int b = fastdiv(px, tb.divHoWo), hw = px - b * HoWo;
         float* zb = zs + (size_t)b * g.ybs + hw;
 #pragma unroll
         for (int mi = 0; mi < MO; ++mi) {
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(WO * WP * 64, 2) void k_band_fwd(
 // Dynamic LDS: [2 dz buffers | basis table | tap shifts | phase table | pixel cell offsets | dump words | halo tile].
 struct BandWTab {
     int n_phase, NGR, HC, span_r, OR0, OC0, cells, n_steps, TPI, n_ptiles;     // TPI: pixel tiles per image; n_ptiles = B * TPI
-    FastDiv divHC, divCells, divTPI;
+    FastDiv divHC, divCells, divTPI, divWo;
     unsigned ph_pack[KAN_BAND_MAX_PHASES];                     // a | b << 8 | first tap << 16 | taps << 24
     unsigned short ph_rt0[KAN_BAND_MAX_PHASES + 1];            // first row tile (grid x) of the phase: phase ph owns NGR * n_rt(ph) tiles
     unsigned short tap_shift[KAN_BAND_MAX_TAPS];
@@ -316,7 +324,8 @@ __global__ __launch_bounds__(WR * 64, 2) void k_band_bwd_weight(
 
     if (tid < KAN_MAX_TABLE) sTab[tid] = bs.tab[tid];
     if (tid < KAN_BAND_MAX_TAPS) sShift[tid] = (int)tb.tap_shift[tid] * (NPS * 4);
-    for (int i = tid; i < tb.cells * NPS + NPS; i += NT) sH[i] = 0.f;
+    if (NPL & 1)                                             // the zero row of an odd plane count (every other word is rewritten by each tile's expansion)
+        for (int i = tid; i < tb.cells; i += NT) sH[i * NPS + NPL] = 0.f;
     __syncthreads();
 
     // A-operand base of this lane's row: tap shift + plane word (rows past the group's end: any valid address, discarded at the store)
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(WR * 64, 2) void k_band_bwd_weight(
         const int v = fastdiv(cell, tb.divHC), jj = cell - v * tb.HC;
         u_vj[k] = v | (jj << 16);
         u_dst[k] = (cell * NPS + ch * P) | (ch << 24);
-        u_ok |= ((ch < NG && cbase + ch < g.C) ? 1u : 0u) << k;
+        u_ok |= ((ch < NG) ? 1u : 0u) << k;                  // the unit exists: written on every tile (zeros outside the image / past the last channel)
     }
 
     f32x16 acc[NI];
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(WR * 64, 2) void k_band_bwd_weight(
     for (int pt = pt0; pt < pt1; ++pt) {
         const int b = fastdiv(pt, tb.divTPI), ti = pt - b * tb.TPI;
         const int p0 = ti * TPX, npx = min(TPX, HoWo - p0);
-        const int ho0 = p0 / g.Wo;
+        const int ho0 = fastdiv(p0, tb.divWo);
         __syncthreads();                                     // previous tile's reads of sH / sCell / sZ are done
         // ---- this tile's first dz step, its pixel -> cell table, its halo
         auto issue_dz = [&](int st, int zb) {
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(WR * 64, 2) void k_band_bwd_weight(
         issue_dz(0, 0);
         if (ti != last_ti) {
             if (tid < TPX) {
-                const int p = p0 + min(tid, npx - 1), ho = p / g.Wo, wo = p - ho * g.Wo;
+                const int p = p0 + min(tid, npx - 1), ho = fastdiv(p, tb.divWo), wo = p - ho * g.Wo;
                 sCell[tid] = ((ho - ho0) * tb.HC + wo) * (NPS * 4);
             }
             last_ti = ti;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(WR * 64, 2) void k_band_bwd_weight(
             for (int k = 0; k < SLOTS; ++k) {
                 const int v = u_vj[k] & 0xffff, jj = u_vj[k] >> 16, ch = u_dst[k] >> 24;
                 const int row = g.sh * (ho0 + v + tb.OR0) + pa, col = g.sw * (jj + tb.OC0) + pb;
-                const bool inb = ((u_ok >> k) & 1u) && (unsigned)row < (unsigned)g.H && (unsigned)col < (unsigned)g.W;
+                const bool inb = ((u_ok >> k) & 1u) && cbase + ch < g.C && (unsigned)row < (unsigned)g.H && (unsigned)col < (unsigned)g.W;
                 const unsigned off = inb ? (unsigned)(b * (int)g.xbs + (cbase + ch) * HW + row * g.W + col) * 4u : KAN_OOB;
                 xa[k] = buf_load(x_rs, off);
                 xb[k] = same_in ? xa[k] : buf_load(xn_rs, off);
@@ -578,8 +587,7 @@ static void band_cfg_pass(const KanGeom* g, const KanBasis* b, int fast, KanBand
     }
     c->cells = vr_max * c->HC;
     c->slots = ceil_div((long long)c->NG * c->cells, c->NT);
-    if (c->slots > 8) return;
-    c->slots = c->slots <= 4 ? 4 : 8;
+    if (c->slots > 6) return;                                       // (one instantiation holds up to six units per thread; unused ones are skipped at run time)
     c->TS = 1;      // taps per barrier step.  Two were measured on every target shape (3 -> 64 3x3: 0.083 -> 0.093 ms; 3 -> 64 k11 s4: 0.86 -> 0.94;
                     // 64 -> 192 k5: 3.22 -> 3.24): the barrier is not what bounds these steps, and the doubled weight buffer costs a workgroup per CU
     const int WBUF = ceil_div(c->TS * c->NPLE * c->TO, 256) * 256;
@@ -662,8 +670,9 @@ int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float*
     BandTab tb;
     memset(&tb, 0, sizeof(tb));
     tb.n_phase = c->n_phase; tb.NGR = c->NGR; tb.HC = c->HC; tb.span_r = c->span_r; tb.OR0 = c->OR0; tb.OC0 = c->OC0; tb.cells = c->cells;
-    tb.n_steps = c->n_steps;
+    tb.n_steps = c->n_steps; tb.nslots = c->slots;
     tb.divHC = make_fastdiv(c->HC); tb.divBlk = make_fastdiv(g->Ho + c->span_r); tb.divCells = make_fastdiv(c->cells); tb.divNGR = make_fastdiv(c->NGR);
+    tb.divHoWo = make_fastdiv(g->Ho * g->Wo); tb.divWo = make_fastdiv(g->Wo);
     for (int ph = 0; ph < c->n_phase; ++ph)
         tb.ph_pack[ph] = (unsigned)c->ph_a[ph] | ((unsigned)c->ph_b[ph] << 8) | ((unsigned)c->ph_tap0[ph] << 16) |
                          ((unsigned)(c->ph_tap0[ph + 1] - c->ph_tap0[ph]) << 24);
@@ -686,7 +695,7 @@ int kan_band_fwd_launch(const float* x, const float* xn, const float* wp, float*
         hipLaunchKernelGGL((k_band_fwd<KIND, F, NGV, 2, MOV, WPV, SL, 1>), grid, dim3(2 * WPV * 64), (size_t)c->lds_bytes, st, x, xn, wp, z, \
                            dg, db, tb, Opad, gps, slab_elems, x_bytes, c->tiles_o);                                                         \
     } while (0)
-#define BAND_SLOTS(KIND, F, NGV, MOV, WPV) do { if (c->slots <= 4) BAND_LAUNCH(KIND, F, NGV, MOV, WPV, 4); else BAND_LAUNCH(KIND, F, NGV, MOV, WPV, 8); } while (0)
+#define BAND_SLOTS(KIND, F, NGV, MOV, WPV) BAND_LAUNCH(KIND, F, NGV, MOV, WPV, 6)
 #define BAND_TILE(KIND, F, NGV)                                                                \
     do {                                                                                       \
         if (c->MO == 1 && c->WP == 4) BAND_SLOTS(KIND, F, NGV, 1, 4);                           \
@@ -726,7 +735,7 @@ int kan_band_bwd_weight_launch(const float* dz, const float* x, const float* xn,
     memset(&tb, 0, sizeof(tb));
     tb.n_phase = c->n_phase; tb.NGR = c->NGR; tb.HC = c->HC; tb.span_r = c->span_r; tb.OR0 = c->OR0; tb.OC0 = c->OC0; tb.cells = c->bw_cells;
     tb.n_steps = c->n_steps; tb.TPI = c->bw_TPI; tb.n_ptiles = c->bw_ptiles;
-    tb.divHC = make_fastdiv(c->HC); tb.divCells = make_fastdiv(c->bw_cells); tb.divTPI = make_fastdiv(c->bw_TPI);
+    tb.divHC = make_fastdiv(c->HC); tb.divCells = make_fastdiv(c->bw_cells); tb.divTPI = make_fastdiv(c->bw_TPI); tb.divWo = make_fastdiv(g->Wo);
     for (int ph = 0; ph < c->n_phase; ++ph)
         tb.ph_pack[ph] = (unsigned)c->ph_a[ph] | ((unsigned)c->ph_b[ph] << 8) | ((unsigned)c->ph_tap0[ph] << 16) |
                          ((unsigned)(c->ph_tap0[ph + 1] - c->ph_tap0[ph]) << 24);

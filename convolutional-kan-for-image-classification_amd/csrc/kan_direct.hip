@@ -282,8 +282,10 @@ struct BandWTab {
     unsigned short tap_shift[KAN_BAND_MAX_TAPS];
 };
 
+// (192 outputs: 96 accumulator registers per lane; the launch bound asks for three 4-wave workgroups per CU, i.e. <= 168 VGPRs -- at 169 the
+//  64 -> 192 layer lost a workgroup per CU and ran 2.46 -> 2.91 ms)
 template <int KIND, int FAST, int NG, int WR, int NI, int SLOTS>
-__global__ __launch_bounds__(WR * 64, 2) void k_band_bwd_weight(
+__global__ __launch_bounds__(WR * 64, (NI == 6 && WR == 4) ? 3 : 2) void k_band_bwd_weight(
     const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ xn, float* __restrict__ dwp,
     DevGeom g, DevBasis bs, BandWTab tb, int Kpad, int Opad, int ptiles_per_split, long long slab_elems, unsigned x_bytes, unsigned dz_bytes,
     int tiles_o) {

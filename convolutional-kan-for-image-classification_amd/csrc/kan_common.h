@@ -304,9 +304,8 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
             if (hb) base = kan_act_fast(bs.act, xa);
             if (!bspline_uniform<false>(bs.order, xb, sTab, bs.nb + bs.order + 1, bs.inv_h, j0, N)) j0 = -8;
         }
-#pragma unroll
-        for (int p = 0; p < KAN_PMAX; ++p)
-            if (p < P) col[p * ld] = (p < hb) ? base : 0.f;
+#pragma unroll 1
+        for (int p = 0; p < P; ++p) col[p * ld] = (p < hb) ? base : 0.f;      // (run-time loop: see kan_planes_each)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (r <= bs.order) {                                     // uniform
@@ -316,11 +315,8 @@ __device__ __forceinline__ void stage_unit(const DevBasis& bs, const float* sTab
             }
         }
     } else {
-        float v[KAN_PMAX];
-        kan_planes<KIND, false>(bs, sTab, xa, xb, v, inb ? c : 0);
-#pragma unroll
-        for (int p = 0; p < KAN_PMAX; ++p)
-            if (p < P) col[p * ld] = inb ? v[p] : 0.f;
+        // generic (run-time P) specs: planes streamed into the LDS column by run-time loops, no register array (kan_device.h: kan_planes_each)
+        kan_planes_each<KIND, false>(bs, sTab, xa, xb, inb ? c : 0, [&](int p, float v) { col[p * ld] = inb ? v : 0.f; });
     }
 }
 

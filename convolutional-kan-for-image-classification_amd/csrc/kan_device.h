@@ -305,3 +305,107 @@ __device__ __forceinline__ void kan_planes(const DevBasis& bs, const float* tabs
         }
     }
 }
+
+// ---------------------------------------------------------------- plane expansion, streamed (round 3)
+// The same planes as kan_planes, handed to `emit(p, value)` one at a time in increasing p by RUN-TIME loops.  The array form above is
+// unrolled over all KAN_PMAX planes with run-time plane counts, which is what made the generic (run-time P) conv kernels 8 000 lines of ISA
+// with 150 - 280 spilled scalar registers (each spill a v_readlane / v_writelane, i.e. a vector instruction next to the fp32 MFMAs).  The
+// generic staging (stage_unit) and the generic bwd-data epilogue use this form; formulas and their order are kan_planes' own.
+template <int KIND, bool DERIV, typename F>
+__device__ __forceinline__ void kan_planes_each(const DevBasis& bs, const float* tabs, float xa, float xb, int c, F&& emit) {
+    const int hb = bs.hb, nb = bs.nb;
+    if (hb) {
+        float base = DERIV ? kan_act_grad(bs.act, xa) : kan_act(bs.act, xa);
+        if ((KIND == KAN_BASIS_RELU || KIND == KAN_BASIS_GRAM) && !DERIV && bs.order != 0) base = 0.f;      // parameter-derivative modes: base plane zero
+        emit(0, base);
+    }
+    if (KIND == KAN_BASIS_BSPLINE) {
+        int j0 = 0; float N[4];
+        const bool ok = bspline_uniform<DERIV>(bs.order, xb, tabs, nb + bs.order + 1, bs.inv_h, j0, N);
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            const int d = j - j0;
+            float val = 0.f;
+            val = d == 0 ? N[0] : val; val = d == 1 ? N[1] : val; val = d == 2 ? N[2] : val; val = d == 3 ? N[3] : val;
+            emit(hb + j, (ok && d >= 0 && d <= bs.order) ? val : 0.f);
+        }
+    } else if (KIND == KAN_BASIS_RBF) {
+        const float dn = bs.p0;
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            const float u = (xb - tabs[j]) / dn;
+            const float e = expf(-(u * u));
+            emit(hb + j, DERIV ? e * (-2.0f * u) / dn : e);
+        }
+    } else if (KIND == KAN_BASIS_FOURIER) {
+        const int G = nb >> 1;
+        float s1, c1;
+        sincosf(xb, &s1, &c1);
+        float ck = c1, sk = s1, kf = 1.f;
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            if (j == G) { ck = c1; sk = s1; kf = 1.f; }
+            const bool is_cos = j < G;
+            emit(hb + j, is_cos ? (DERIV ? -kf * sk : ck) : (DERIV ? kf * ck : sk));
+            const float cn = ck * c1 - sk * s1, sn = sk * c1 + ck * s1;
+            ck = cn; sk = sn; kf += 1.f;
+        }
+    } else if (KIND == KAN_BASIS_RELU) {
+        const float* lo = bs.ctab + (size_t)c * 2 * nb;
+        const float* hi = lo + nb;
+        const float r = bs.p0;
+        const int mode = DERIV ? 3 : bs.order;
+#pragma unroll 1
+        for (int j = 0; j < nb; ++j) {
+            const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(hi[j] - xb, 0.f);
+            const float q = x1 * x2 * r;
+            const float q2 = 2.0f * q * r;
+            emit(hb + j, mode == 0 ? q * q : mode == 1 ? -(q2 * x2) : mode == 2 ? q2 * x1 : q2 * (x2 - x1));
+        }
+    } else if (KIND == KAN_BASIS_GRAM) {
+        const float* cf = bs.ctab;
+        const float t = tanhf(xb), chain = 1.0f - t * t;
+        const int mode = DERIV ? 0 : bs.order;
+        float Pm = 1.f, Pc = t, Dm = 0.f, Dc = 1.f, Qm = 0.f, Qc = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < nb; ++k) {
+            const float P = k == 0 ? 1.f : Pc, D = k == 0 ? 0.f : Dc, Q = k == 0 ? 0.f : Qc;
+            emit(hb + k, DERIV ? kan_act_grad(bs.act, P) * D * chain : mode == 0 ? kan_act(bs.act, P) : kan_act_grad(bs.act, P) * Q);
+            if (k >= 1 && k + 1 < nb) {
+                const float cc = cf[k + 1];
+                const float Pn = t * Pc - cc * Pm, Dn = Pc + t * Dc - cc * Dm;
+                const float Qn = t * Qc - cc * Qm - (k + 1 == mode + 1 ? Pm : 0.f);
+                Pm = Pc; Pc = Pn; Dm = Dc; Dc = Dn; Qm = Qc; Qc = Qn;
+            }
+        }
+    } else if (KIND == KAN_BASIS_POLY) {
+        const float t = bs.order ? tanhf(xb) : xb;
+        const float chain = bs.order ? (1.0f - t * t) : 1.0f;
+        float Tm = tabs[0], Tc = tabs[1] * t + tabs[2];
+        float Dm = 0.f, Dc = tabs[1];
+        emit(hb, DERIV ? 0.f : Tm);
+#pragma unroll 1
+        for (int k = 1; k < nb; ++k) {
+            emit(hb + k, DERIV ? Dc * chain : Tc);
+            if (k + 1 < nb) {
+                const float A = tabs[3 * k], B = tabs[3 * k + 1], Cc = tabs[3 * k + 2];      // coefficients of T_{k+1}
+                const float sA = A * t + B;
+                const float Tn = sA * Tc + Cc * Tm, Dn = A * Tc + sA * Dc + Cc * Dm;
+                Tm = Tc; Tc = Tn; Dm = Dc; Dc = Dn;
+            }
+        }
+    } else {      // Chebyshev
+        const float t0 = tanhf(xb);
+        const float t = fminf(fmaxf(t0, bs.p0), bs.p1);
+        const bool inside = (t0 >= bs.p0) && (t0 <= bs.p1);
+        const float chain = inside ? (1.0f - t0 * t0) : 0.f;
+        float Tm = 1.f, Tc = t, Um = 0.f, Uc = 1.f;
+        emit(hb, DERIV ? 0.f : 1.f);
+#pragma unroll 1
+        for (int k = 1; k < nb; ++k) {
+            emit(hb + k, DERIV ? (float)k * Uc * chain : Tc);
+            const float Tn = 2.f * t * Tc - Tm; Tm = Tc; Tc = Tn;
+            const float Un = 2.f * t * Uc - Um; Um = Uc; Uc = Un;
+        }
+    }
+}

@@ -1116,16 +1116,12 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
             const size_t idx = (size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_);
             const float xa = x[idx];
             const float xb = same_in ? xa : xn[idx];
-            float d[KAN_PMAX];
-            kan_planes<KIND, true>(bs, sTab, xa, xb, d, c);
             float s_base = 0.f, s_bas = 0.f;
-#pragma unroll
-            for (int p = 0; p < KAN_PMAX; ++p) {
-                if (p < P) {
-                    float gv = smem[(cl * P + p) * TP + pxl];
-                    if (p < bs.hb) s_base += d[p] * gv; else s_bas += d[p] * gv;
-                }
-            }
+            const float* Gc = smem + (cl * P) * TP + pxl;
+            kan_planes_each<KIND, true>(bs, sTab, xa, xb, c, [&](int p, float d) {      // derivative planes streamed by run-time loops (kan_device.h)
+                const float gv = Gc[p * TP];
+                if (p < bs.hb) s_base += d * gv; else s_bas += d * gv;
+            });
             if (split_out) { dxs[idx] = s_base; dxns[idx] = s_bas; }
             else dxs[idx] = s_base + s_bas;
         }

@@ -1130,36 +1130,21 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
             // the same G tile.  The coefficients are layer-global, so every workgroup would hit the same few words: a thread sums over its
             // channels, the wave adds up, and lane 0 adds to one of 64 slot rows dpar[slot][n] (the host sums the rows).
             const int nb = bs.nb;
-            float am[KAN_PMAX];
-#pragma unroll
-            for (int m = 0; m < KAN_PMAX; ++m) am[m] = 0.f;
-            for (int cl = ol0; cl < CH; cl += 2) {
-                const int c = (ct * 2 + half) * CH + cl;
-                if (c >= g.C) continue;
-                const float xb = pv ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
-#pragma unroll
-                for (int m = 1; m < KAN_PMAX - 1; ++m) {
-                    if (m < nb - 1) {                                              // modes 1 .. nb - 2: derivative w.r.t. c_{m+1}
-                        DevBasis bm = bs; bm.order = m;
-                        float v[KAN_PMAX];
-                        kan_planes<KAN_BASIS_GRAM, false>(bm, sTab, xb, xb, v, c);
-                        float sacc = 0.f;
-#pragma unroll
-                        for (int p = 0; p < KAN_PMAX; ++p)
-                            if (p < P) sacc += v[p] * smem[(cl * P + p) * TP + pxl];
-                        am[m] += pv ? sacc : 0.f;
-                    }
-                }
-            }
             const unsigned slot = (blockIdx.x + 7u * blockIdx.y + 13u * blockIdx.z) & 63u;
-#pragma unroll
-            for (int m = 1; m < KAN_PMAX - 1; ++m) {
-                if (m < nb - 1) {
-                    float v = am[m];
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                    if (lane == 0) atomicAdd(dpar + (size_t)slot * nb + m + 1, v);
+#pragma unroll 1
+            for (int m = 1; m < nb - 1; ++m) {                                     // modes 1 .. nb - 2: derivative w.r.t. c_{m+1}
+                DevBasis bm = bs; bm.order = m;
+                float am = 0.f;
+                for (int cl = ol0; cl < CH; cl += 2) {
+                    const int c = (ct * 2 + half) * CH + cl;
+                    if (c >= g.C || !pv) continue;
+                    const float xb = x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)];
+                    const float* Gc = smem + (cl * P) * TP + pxl;
+                    kan_planes_each<KAN_BASIS_GRAM, false>(bm, sTab, xb, xb, c, [&](int p, float v) { am += v * Gc[p * TP]; });
                 }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) am += __shfl_xor(am, off, 64);
+                if (lane == 0) atomicAdd(dpar + (size_t)slot * nb + m + 1, am);
             }
         }
         if (KIND == KAN_BASIS_RELU && dpar) {

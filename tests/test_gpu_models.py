@@ -96,6 +96,70 @@ def test_cheby_alexnet(gpu_lib):
     run("cheby_alexnet", alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4))
 
 
+def test_cheby_alexnet_config5_full_batch(gpu_lib):
+    """BASELINE.json configs[4] at its FULL size (ChebyKAN-AlexNet, 128 x 3x224x224) -- too big for the CPU oracle, so it is tied to the
+    reference through size-independent properties of the path (samples are independent through conv, per-sample InstanceNorm and PReLU;
+    the summed loss is additive over samples):
+      (a) sample 0 of the batch IS the reference fixture's image: its logits inside the 128-image launch match the reference's fp32 and
+          fp64 passes at the calibrated model-level tolerance;
+      (b) every image's logits inside the full launch equal those of the chunked launches (1 + 31 + 32 + 64 images: other tile counts,
+          split-K factors and kernel choices), and so does the input gradient;
+      (c) every parameter gradient of the full launch equals the sum over the chunks; the 1-image chunk's gradients are the fixture's
+          (reference) gradients, so the chain full batch -> chunks -> reference is closed inside this test."""
+    from convkan_amd.models import alexnet_kan
+    d = np.load(os.path.join(GOLDEN, "model_cheby_alexnet.npz"))
+    tol, spread = calibrated_tolerances(d)
+    torch.manual_seed(0)
+    model = alexnet_kan(num_classes=10, kan_conv="ChebyKAN", degree=4)
+    model_fill(model)
+    model = model.cuda().eval()                              # eval: the head's Dropout is inert, the conv path is the same in both modes
+    names = [n for n, _ in model.named_parameters()]
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(128, 3, 224, 224, generator=g)
+    x[0] = torch.from_numpy(d["x"])[0]
+    t = torch.randint(0, 10, (128,), generator=g)
+    t[0] = int(d["t"][0])
+    x, t = x.cuda(), t.cuda()
+
+    def step(lo, hi):
+        model.zero_grad(set_to_none=True)
+        xi = x[lo:hi].clone().requires_grad_(True)
+        logits = model(xi)
+        F.cross_entropy(logits, t[lo:hi], reduction="sum").backward()
+        torch.cuda.synchronize()
+        return logits.detach().double(), xi.grad.double(), [p.grad.double().clone() for _, p in model.named_parameters()]
+
+    full_logits, full_dx, full_g = step(0, 128)
+    # (a) the fixture image inside the 128-image launch
+    for sfx in ("", "64"):
+        ref = d["logits" + sfx].astype(np.float64)
+        err = float(np.abs(full_logits[0:1].cpu().numpy() - ref).max() / np.abs(ref).max())
+        print(f"[config 5 full] sample 0 logits vs reference fp{sfx or 32}: {err:.2e} (tol {tol['logits']:.1e})")
+        assert err <= tol["logits"], (sfx, err)
+    # (b) + (c) chunked launches
+    sum_g = [torch.zeros_like(v) for v in full_g]
+    worst = dict(logits=0.0, dx=0.0)
+    for lo, hi in ((0, 1), (1, 32), (32, 64), (64, 128)):
+        lg, dx, gs = step(lo, hi)
+        worst["logits"] = max(worst["logits"], float((lg - full_logits[lo:hi]).abs().max() / full_logits.abs().max()))
+        worst["dx"] = max(worst["dx"], float((dx - full_dx[lo:hi]).abs().max() / full_dx.abs().max()))
+        for a, b in zip(sum_g, gs):
+            a += b
+        if (lo, hi) == (0, 1):                               # the fixture's own step (mean == sum for one image)
+            gn = np.array([float(v.norm()) for v in gs])
+            rel = np.abs(gn - d["grad_norm"]) / (d["grad_norm"] + 1e-30)
+            print(f"[config 5 full] 1-image chunk vs reference gradient norms: {rel.max():.2e} at {names[int(rel.argmax())]} (tol {tol['grad_norm']:.1e})")
+            assert rel.max() <= tol["grad_norm"], (names[int(rel.argmax())], rel.max())
+    gerr = [float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(sum_g, full_g)]
+    nerr = [abs(float(a.norm()) - float(b.norm())) / (float(b.norm()) + 1e-30) for a, b in zip(sum_g, full_g)]
+    k = int(np.argmax(gerr))
+    print(f"[config 5 full] full launch vs chunks: logits {worst['logits']:.2e} (tol {tol['logits']:.1e})  dx {worst['dx']:.2e} (tol {tol['grad_slice']:.1e})  "
+          f"gradient max {gerr[k]:.2e} at {names[k]} (tol {tol['grad_slice']:.1e})  norm {max(nerr):.2e} (tol {tol['grad_norm']:.1e})")
+    assert worst["logits"] <= tol["logits"] and worst["dx"] <= tol["grad_slice"], worst
+    assert gerr[k] <= tol["grad_slice"], (names[k], gerr[k])
+    assert max(nerr) <= tol["grad_norm"], max(nerr)
+
+
 def _capture(model, layer_type, xin, tt):
     """One train-mode forward + CE + backward; per KAN layer (index in model.features): input x, output y, dL/dy, dL/dx."""
     rec, hooks = {}, []

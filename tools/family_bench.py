@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """ms/step (fwd+loss+bwd, bs 256, 3x32x32) of KAN-VGG11 built with each registered conv-KAN family."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn.functional as F
 import convkan_amd as K
 from convkan_amd.models import vggkan

@@ -99,14 +99,19 @@ def test_cheby_alexnet(gpu_lib):
 def test_cheby_alexnet_config5_full_batch(gpu_lib):
     """BASELINE.json configs[4] at its FULL size (ChebyKAN-AlexNet, 128 x 3x224x224) -- too big for the CPU oracle, so it is tied to the
     reference through size-independent properties of the path (samples are independent through conv, per-sample InstanceNorm and PReLU;
-    the summed loss is additive over samples):
+    the weight gradient is additive over samples):
       (a) sample 0 of the batch IS the reference fixture's image: its logits inside the 128-image launch match the reference's fp32 and
-          fp64 passes at the calibrated model-level tolerance;
-      (b) every image's logits inside the full launch equal those of the chunked launches (1 + 31 + 32 + 64 images: other tile counts,
-          split-K factors and kernel choices), and so does the input gradient;
-      (c) every parameter gradient of the full launch equals the sum over the chunks; the 1-image chunk's gradients are the fixture's
-          (reference) gradients, so the chain full batch -> chunks -> reference is closed inside this test."""
+          fp64 passes at the calibrated model-level tolerance, and every image's logits equal those of chunked launches (1 + 31 + 32 + 64);
+      (b) every conv-KAN layer, on the input and the upstream gradient it actually saw inside the 128-image step, is re-run alone in chunks
+          of 32 images (other tile counts, split-K factors and kernel choices): outputs and input gradients of the full launch equal the
+          chunks' and every parameter gradient equals the sum over the chunks, at 2 x the stated layer tolerances (two launches, each within
+          the stated tolerance of the exact result);
+      (c) the 1-image chunk of the model is the fixture's own step: its gradients match the reference's.
+    Model-level gradients of the full launch against the sum of chunked MODEL steps are printed, not asserted: MaxPool2d(3, 2) argmax and
+    PReLU decisions re-route under the 1e-6 forward differences between launch configurations (measured round 3: logits agree to 1e-6,
+    gradients differ by up to 2e-1 max-normalised while every layer alone agrees to 2e-6 -- tools/probe/chunk_consistency.py)."""
     from convkan_amd.models import alexnet_kan
+    from convkan_amd.layers import ChebyKANConv2DLayer
     d = np.load(os.path.join(GOLDEN, "model_cheby_alexnet.npz"))
     tol, spread = calibrated_tolerances(d)
     torch.manual_seed(0)
@@ -129,14 +134,29 @@ def test_cheby_alexnet_config5_full_batch(gpu_lib):
         torch.cuda.synchronize()
         return logits.detach().double(), xi.grad.double(), [p.grad.double().clone() for _, p in model.named_parameters()]
 
+    # the full step, with every conv-KAN layer's input, output and both gradients recorded
+    rec, hooks = {}, []
+    for i, f in enumerate(model.features):
+        if isinstance(f, ChebyKANConv2DLayer):
+            def pre(mod, args, i=i):
+                rec.setdefault(i, {})["x"] = args[0].detach()
+                if args[0].requires_grad:
+                    args[0].register_hook(lambda gr, i=i: rec[i].__setitem__("dx", gr.detach()))
+            def post(mod, args, out, i=i):
+                rec[i]["y"] = out.detach()
+                out.register_hook(lambda gr, i=i: rec[i].__setitem__("dy", gr.detach()))
+            hooks += [f.register_forward_pre_hook(pre), f.register_forward_hook(post)]
     full_logits, full_dx, full_g = step(0, 128)
-    # (a) the fixture image inside the 128-image launch
+    for h in hooks:
+        h.remove()
+    layer_grads = {i: {n: p.grad.double().clone() for n, p in model.features[i].named_parameters()} for i in rec}
+
+    # (a) the fixture image inside the 128-image launch; logits of chunked launches
     for sfx in ("", "64"):
         ref = d["logits" + sfx].astype(np.float64)
         err = float(np.abs(full_logits[0:1].cpu().numpy() - ref).max() / np.abs(ref).max())
         print(f"[config 5 full] sample 0 logits vs reference fp{sfx or 32}: {err:.2e} (tol {tol['logits']:.1e})")
         assert err <= tol["logits"], (sfx, err)
-    # (b) + (c) chunked launches
     sum_g = [torch.zeros_like(v) for v in full_g]
     worst = dict(logits=0.0, dx=0.0)
     for lo, hi in ((0, 1), (1, 32), (32, 64), (64, 128)):
@@ -145,19 +165,39 @@ def test_cheby_alexnet_config5_full_batch(gpu_lib):
         worst["dx"] = max(worst["dx"], float((dx - full_dx[lo:hi]).abs().max() / full_dx.abs().max()))
         for a, b in zip(sum_g, gs):
             a += b
-        if (lo, hi) == (0, 1):                               # the fixture's own step (mean == sum for one image)
+        if (lo, hi) == (0, 1):                               # (c) the fixture's own step (mean == sum for one image)
             gn = np.array([float(v.norm()) for v in gs])
             rel = np.abs(gn - d["grad_norm"]) / (d["grad_norm"] + 1e-30)
             print(f"[config 5 full] 1-image chunk vs reference gradient norms: {rel.max():.2e} at {names[int(rel.argmax())]} (tol {tol['grad_norm']:.1e})")
             assert rel.max() <= tol["grad_norm"], (names[int(rel.argmax())], rel.max())
     gerr = [float((a - b).abs().max() / (b.abs().max() + 1e-30)) for a, b in zip(sum_g, full_g)]
-    nerr = [abs(float(a.norm()) - float(b.norm())) / (float(b.norm()) + 1e-30) for a, b in zip(sum_g, full_g)]
     k = int(np.argmax(gerr))
-    print(f"[config 5 full] full launch vs chunks: logits {worst['logits']:.2e} (tol {tol['logits']:.1e})  dx {worst['dx']:.2e} (tol {tol['grad_slice']:.1e})  "
-          f"gradient max {gerr[k]:.2e} at {names[k]} (tol {tol['grad_slice']:.1e})  norm {max(nerr):.2e} (tol {tol['grad_norm']:.1e})")
-    assert worst["logits"] <= tol["logits"] and worst["dx"] <= tol["grad_slice"], worst
-    assert gerr[k] <= tol["grad_slice"], (names[k], gerr[k])
-    assert max(nerr) <= tol["grad_norm"], max(nerr)
+    print(f"[config 5 full] model step, full launch vs chunked steps: logits {worst['logits']:.2e} (tol {tol['logits']:.1e}); not asserted (pool / PReLU "
+          f"re-routing): dx {worst['dx']:.2e}, gradient max {gerr[k]:.2e} at {names[k]}")
+    assert worst["logits"] <= tol["logits"], worst
+
+    # (b) every layer alone on what it saw in the full step
+    bad = []
+    for i in sorted(rec):
+        layer, r = model.features[i], rec[i]
+        sums, ey, ex = None, 0.0, 0.0
+        for lo in range(0, 128, 32):
+            layer.zero_grad(set_to_none=True)
+            xi = r["x"][lo:lo + 32].clone().requires_grad_(True)
+            y = layer(xi)
+            y.backward(r["dy"][lo:lo + 32])
+            torch.cuda.synchronize()
+            ey = max(ey, float((y.detach() - r["y"][lo:lo + 32]).abs().max() / r["y"].abs().max()))
+            if "dx" in r:
+                ex = max(ex, float((xi.grad - r["dx"][lo:lo + 32]).abs().max() / r["dx"].abs().max()))
+            gl = {n: p.grad.double().clone() for n, p in layer.named_parameters()}
+            sums = gl if sums is None else {n: sums[n] + gl[n] for n in gl}
+        eg = {n: float((sums[n] - layer_grads[i][n]).abs().max() / (layer_grads[i][n].abs().max() + 1e-30)) for n in sums}
+        print(f"[config 5 full] features.{i} {tuple(r['x'].shape)}: full launch vs 4 x 32 images  y {ey:.2e}  dx {ex:.2e}  "
+              + "  ".join(f"{n} {v:.2e}" for n, v in eg.items()))
+        if ey > 2e-5 or ex > 2e-5 or max(eg.values()) > 1e-4:
+            bad.append((i, ey, ex, eg))
+    assert not bad, bad
 
 
 def _capture(model, layer_type, xin, tt):

@@ -1138,7 +1138,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
                 for (int cl = ol0; cl < CH; cl += 2) {
                     const int c = (ct * 2 + half) * CH + cl;
                     if (c >= g.C || !pv) continue;
-                    const float xb = x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)];
+                    const float xb = (same_in ? x : xn)[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)];      // the tensor the basis reads
                     const float* Gc = smem + (cl * P) * TP + pxl;
                     kan_planes_each<KAN_BASIS_GRAM, false>(bm, sTab, xb, xb, c, [&](int p, float v) { am += v * Gc[p * TP]; });
                 }
@@ -1158,7 +1158,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
             for (int cl = ol0; cl < CH; cl += 2) {                                  // (wave-uniform)
                 const int c = (ct * 2 + half) * CH + cl;
                 if (c >= g.C) continue;
-                const float xb = pv ? x[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;
+                const float xb = pv ? (same_in ? x : xn)[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;      // the tensor the basis reads
                 const float* lo = bs.ctab + (size_t)c * 2 * nb;
                 for (int j = 0; j < nb; ++j) {
                     const float gv = pv ? smem[(cl * P + hb + j) * TP + pxl] : 0.f;

@@ -57,7 +57,7 @@ class ReLUConvNDLayer(_HipLayer):
             nn.init.kaiming_uniform_(conv.weight, nonlinearity='linear')
 
     def conv_spec(self) -> ops.ConvSpec:
-        return self._spec(kind=L.BASIS_RELU, n_basis=self.g + self.k, order=0, act=_act_code(self.base_activation), p0=float(self.r),
+        return self._spec(kind=L.BASIS_RELU, n_basis=self.g + self.k, order=0, act=_act_code(self.base_activation, host_ok=True), p0=float(self.r),
                           p1=0.0, table=())
 
     def forward(self, x):
@@ -66,7 +66,9 @@ class ReLUConvNDLayer(_HipLayer):
         if self.dropout is not None:
             x = self.dropout(x)                                  # relu_kan_layers.py:120-121: on the input, both branches see it
         phases = torch.stack([self.phase_low.reshape(cg, n), self.phase_high.reshape(cg, n)], dim=1)
-        z = ops.kan_conv_phased(self.conv_spec(), self._lift(x), phases, self._w(self.base_conv), self._w(self.relukan_conv))
+        xa, xb = self._base_input(x)                              # (act(x), x) when the host applies the activation (no device functor for the module)
+        z = ops.kan_conv_phased(self.conv_spec(), self._lift(xa), phases, self._w(self.base_conv), self._w(self.relukan_conv),
+                                xn=self._lift(xb) if xb is not None else None)
         if _fusable_instnorm(self.layer_norm):
             gam, bet = self._norm_affine(self.layer_norm)
             y = ops.instance_norm(z, torch.cat(gam) if gam is not None else None, torch.cat(bet) if bet is not None else None,

@@ -507,15 +507,16 @@ def _is_depthwise(spec: ConvSpec, x, w_basis) -> bool:
 
 class _KanConvPhased(torch.autograd.Function):
     """Conv stage of a basis with trainable per-channel parameters (ReLU-KAN: relu_kan_layers.py:118-136).
-    args: spec, x, phases [Cg, 2, n] (phase_low, phase_high per channel), *[w_base_g], *[w_basis_g].
+    args: spec, x, xn (or None: the basis reads x), phases [Cg, 2, n] (phase_low, phase_high per channel), *[w_base_g], *[w_basis_g].
 
     d phase[c][m][j] = sum_{b,pixel} G_{c,j} * d basis_j / d phase_m, where G = dgrad(dz, W_basis) is never materialised:
     the sum is regrouped as  sum_{group,o,tap} W_basis[o][c*n+j][tap] * wgrad(d basis / d phase_m, dz)[o][c*n+j][tap],
     i.e. the weight-gradient kernel run on the parameter-derivative planes, contracted with the weights."""
 
     @staticmethod
-    def forward(ctx, spec: ConvSpec, x, phases, *weights):
+    def forward(ctx, spec: ConvSpec, x, xn, phases, *weights):
         x = _require(x, "x")
+        xn = _require(xn, "xn") if xn is not None else None      # host-applied base activation: x = act(input) feeds the base branch, xn = input the basis
         phases = _require(phases, "phases")
         weights = [_require(w, "weight") for w in weights]
         w_base, w_basis = _split_weights(spec, weights)
@@ -523,32 +524,36 @@ class _KanConvPhased(torch.autograd.Function):
         want = (x.shape[1] // G, 2, spec.n_basis) if spec.kind == L.BASIS_RELU else (spec.n_basis,)
         if tuple(phases.shape) != want:
             raise L.KanConvError(f"parameter table {tuple(phases.shape)} != {want} for basis kind {spec.kind}")
+        need_dgrad = bool(ctx.needs_input_grad[1]) or (xn is not None and bool(ctx.needs_input_grad[2]))
         with torch.cuda.device(x.device):
-            z, packed, geom, _, plan = _conv_forward(spec, x, None, w_base, w_basis, bool(ctx.needs_input_grad[1]), phases)
+            z, packed, geom, _, plan = _conv_forward(spec, x, xn, w_base, w_basis, need_dgrad, phases)
             z = _sum_slabs(z, geom.B, z.shape[2], geom.Ho * geom.Wo)
         ctx.spec = spec
+        ctx.two = xn is not None
         ctx.layout = (packed[0] is not None, packed[1] is not None)
-        ctx.save_for_backward(x, phases, *w_basis, *[t for t in packed if t is not None])
+        ctx.save_for_backward(x, phases, *w_basis, *[t for t in packed if t is not None], *([xn] if xn is not None else []))
         return z
 
     @staticmethod
     def backward(ctx, dz):
         spec, G = ctx.spec, ctx.spec.groups
-        saved = ctx.saved_tensors
+        saved = list(ctx.saved_tensors)
+        xn = saved.pop() if ctx.two else None
         x, phases = saved[0], saved[1]
         w_basis = saved[2:2 + G]
         packed = _unflatten(ctx.layout, list(saved[2 + G:]))
-        need_x, need_p, need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[2], any(ctx.needs_input_grad[3:])
+        need_x, need_xn = ctx.needs_input_grad[1], (ctx.two and ctx.needs_input_grad[2])
+        need_p, need_w = ctx.needs_input_grad[3], any(ctx.needs_input_grad[4:])
         dz = dz.contiguous()
-        dph = None
+        dph = dxn = None
         with torch.cuda.device(x.device):
             # ReLU-KAN / Gram: when the input gradient is computed anyway, its launch also accumulates the parameter gradients from the same G tiles
             # (kan_conv_bwd_data_params); otherwise (first layer of a model, depthwise groups) two more weight-gradient passes deliver them
-            in_epilogue = need_p and need_x and not _is_depthwise(spec, x, w_basis)
+            in_epilogue = need_p and (need_x or need_xn) and not _is_depthwise(spec, x, w_basis)
             dpar = None
             if in_epilogue:                                    # ReLU-KAN: [Cg, 2, n] directly; Gram: 64 slot rows of partial sums
                 dpar = torch.zeros_like(phases) if spec.kind == L.BASIS_RELU else phases.new_zeros((64, spec.n_basis))
-            dx, _, dwb, dws = _conv_backward(spec, x, None, packed, dz, need_x, False, need_w, phases, dparams=dpar)
+            dx, dxn, dwb, dws = _conv_backward(spec, x, xn, packed, dz, need_x, need_xn, need_w, phases, dparams=dpar)
             if in_epilogue:
                 dph = dpar if spec.kind == L.BASIS_RELU else dpar.sum(dim=0)
             if need_p and not in_epilogue:
@@ -556,7 +561,7 @@ class _KanConvPhased(torch.autograd.Function):
                 W = torch.stack(list(w_basis)).view(G, -1, Cg, n, spec.kernel[0] * spec.kernel[1])
 
                 def factor(mode):                               # wgrad of the parameter-derivative planes, times the weights
-                    _, _, _, dwm = _conv_backward(spec, x, None, packed, dz, False, False, True, phases, mode)
+                    _, _, _, dwm = _conv_backward(spec, x, xn, packed, dz, False, False, True, phases, mode)
                     return W * torch.stack(list(dwm)).view_as(W)
                 if spec.kind == L.BASIS_RELU:                  # per-channel phases [Cg, 2, n]
                     dph = torch.stack([factor(mode).sum(dim=(0, 1, 4)) for mode in (1, 2)], dim=1)
@@ -564,7 +569,7 @@ class _KanConvPhased(torch.autograd.Function):
                     dph = torch.zeros_like(phases)
                     for mode in range(1, n - 1):
                         dph[mode + 1] = factor(mode).sum()
-        return (None, dx if need_x else None, dph) + _flat_grads(spec, dwb, dws)
+        return (None, dx if need_x else None, dxn if need_xn else None, dph) + _flat_grads(spec, dwb, dws)
 
 
 def _cat(ts: Sequence[Optional[torch.Tensor]]) -> Optional[torch.Tensor]:
@@ -793,14 +798,14 @@ def kan_conv(spec: ConvSpec, x: torch.Tensor, xn: Optional[torch.Tensor], w_base
 
 
 def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_base: Sequence[torch.Tensor],
-                    w_basis: Sequence[torch.Tensor]) -> torch.Tensor:
+                    w_basis: Sequence[torch.Tensor], xn: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Conv stage of a basis with trainable parameters held in device memory, differentiable in them: ReLU-KAN
     (`phases` = [channels per group, 2, n_basis]: low, high) or Gram (`phases` = [n_basis] recurrence coefficients c_k)."""
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     n = _image_runs(spec, x, sum(w.shape[0] for w in w_basis))
     if n is not None:
-        return _by_image_runs(lambda a, _: _KanConvPhased.apply(spec, a, phases, *ws), n, x)
-    return _KanConvPhased.apply(spec, x, phases, *ws)
+        return _by_image_runs(lambda a, b: _KanConvPhased.apply(spec, a, b, phases, *ws), n, x, xn)
+    return _KanConvPhased.apply(spec, x, xn, phases, *ws)
 
 
 def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Tensor], w_basis: Sequence[torch.Tensor],

@@ -197,6 +197,8 @@ RELU_CASES = [
     C("relu", "wide", 3, 20, 40, 6, 6, extra={"g": 4, "k": 3}),
     C("relu", "depthwise_bn", 3, 4, 8, 8, 8, groups=4, norm="bn"),
     C("relu", "1d_k3s2", 2, 4, 6, 1, 33, ndim=1, s=2),        # (the 1-D shim drops base_activation: relu_kan_layers.py:183-187)
+    C("relu", "act_mish", 2, 3, 4, 8, 8, act="mish"),         # a module without a device functor: host-applied on the base branch (round 3)
+    C("relu", "act_softplus_s2g2", 3, 4, 6, 9, 7, s=2, groups=2, act="softplus", xs=1.5),
 ]
 
 

@@ -235,11 +235,12 @@ def test_factory_signatures_and_same_padding():
     assert list(wrapped.state_dict())[0] == "module.base_conv.0.weight"
     assert type(F["LucasKAN"](4, 6, 3, l1_decay=0.01)).__name__ == "L1" and type(F["conv"](3, 8, 3, l1_decay=0.1)[0]).__name__ == "L1"
     # a base_activation without a device functor is applied by the host (identity functor + two-input kernels) where the
-    # layer has that form; the families with trainable basis parameters still refuse it
+    # layer has that form -- ReLU-KAN included since round 3 (relu_kan_layers.py:57 takes any module).  GRAM passes its PLANES through the
+    # activation inside the kernel (gram_kan_layers.py:181), so only the device functors serve it; its 1-D / 2-D / 3-D classes fix SiLU anyway (:203-231)
     soft = K.KANConv2DLayer(3, 4, 3, base_activation=nn.Softplus)
     assert soft.conv_spec().act == L.ACT_IDENTITY and isinstance(soft.base_activation, nn.Softplus)
-    with pytest.raises(NotImplementedError, match="HIP functor"):
-        K.ReLUKANConv2DLayer(3, 4, 3, base_activation=nn.Softplus).conv_spec()
+    rsoft = K.ReLUKANConv2DLayer(3, 4, 3, base_activation=nn.Softplus)
+    assert rsoft.conv_spec().act == L.ACT_IDENTITY and isinstance(rsoft.base_activation, nn.Softplus)
 
 
 def test_no_cpu_fallback():

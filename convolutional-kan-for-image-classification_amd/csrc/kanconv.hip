@@ -2055,13 +2055,18 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// General MaxPool2d(k, s) (no padding, floor mode: the AlexNet pattern MaxPool2d(3, 2), kan_alexnet.py:38-42) fused behind the PReLU in the generic
+// norm kernels: windows overlap, so the backward of an element sums the pooled gradients of the <= ceil(k/s)^2 windows that picked it.  k == 0: not used
+// (the even-plane 2x2 path below / in the register kernels).
+struct PoolGeo { int k, s, Hp, Wp, nc; FastDiv divWp, divS, divK, divNc; int lds; };      // nc = ceil(k / s): window classes per axis      // lds: the plane (forward) / its pooled gradient + indices (backward) are staged in LDS
+
 template <int G>
 __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* z, int n_slabs, long long slab_elems,     // z_out may alias z (slab 0)
                                                       float* z_out, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, const float* __restrict__ prelu_a,
                                                       float* __restrict__ y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
                                                       int n_planes, int Cn, int HW, long long bstride, float eps, int prelu_span,
-                                                      unsigned char* __restrict__ pidx, int W, FastDiv divW) {
+                                                      unsigned char* __restrict__ pidx, int W, FastDiv divW, PoolGeo pg) {
     const int tid = threadIdx.x, sub = tid % G;
     const int plane = blockIdx.x * (256 / G) + tid / G;
     const bool act = plane < n_planes;
@@ -2093,7 +2098,38 @@ __global__ __launch_bounds__(256) void k_in_prelu_fwd(const float* z, int n_slab
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
     const bool has_p = prelu_a != nullptr;
     const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;     // one slope per `prelu_span` channels (0: one for all)
-    if (pidx) {
+    if (pidx && pg.k) {
+        // general MaxPool2d(k, s): y and pidx are the dense pooled [B][Cn][Hp][Wp] tensors, pidx = dh * k + dw of the maximum (first maximum in
+        // scan order, NaN wins: torch's max_pool2d)
+        const int Q = pg.Hp * pg.Wp;
+        const size_t pbase = (size_t)plane * Q;
+        extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+        float* mine = (float*)pool_smem + (size_t)(tid / G) * HW;      // this plane's activated values (pg.lds): every element is normalised once,
+        if (pg.lds) {                                                  // every window then reads LDS (was: 9 global reads + 9 normalisations per output)
+            for (int i = sub; i < HW; i += G) {
+                const float n = (z_out[base + i] - mu) * rs * ga + be;
+                mine[i] = (has_p && !(n > 0.f)) ? a * n : n;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // a plane's G lanes sit in one wave: LDS serves a wave's accesses in order
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        for (int q = sub; q < Q; q += G) {
+            const int hp = fastdiv(q, pg.divWp), wp = q - hp * pg.Wp, i0 = hp * pg.s * W + wp * pg.s;
+            float best = 0.f; int arg = 0; bool first = true;
+            for (int dh = 0; dh < pg.k; ++dh)
+                for (int dw = 0; dw < pg.k; ++dw) {
+                    float v;
+                    if (pg.lds) v = mine[i0 + dh * W + dw];
+                    else {
+                        const float n = (z_out[base + i0 + dh * W + dw] - mu) * rs * ga + be;
+                        v = (has_p && !(n > 0.f)) ? a * n : n;
+                    }
+                    if (first || v > best || v != v) { best = v; arg = dh * pg.k + dw; first = false; }
+                }
+            y[pbase + q] = best; pidx[pbase + q] = (unsigned char)arg;
+        }
+    } else if (pidx) {
         // fused MaxPool2d(2, 2) (the VGG pattern: kan_vgg.py:97-101 puts one right after the layer): y and pidx are the dense
         // pooled [B][Cn][H/2][W/2] tensors, pidx the position 2*dh + dw of the maximum -- first maximum in scan order, NaN wins,
         // as torch's max_pool2d picks it.  The full-size activation is never written.
@@ -2126,7 +2162,7 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
                                                       const float* __restrict__ prelu_a, float* __restrict__ dz,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dprelu,
                                                       int n_planes, int Cn, int HW, long long bstride, int prelu_span,
-                                                      const unsigned char* __restrict__ pidx, int W, FastDiv divW) {
+                                                      const unsigned char* __restrict__ pidx, int W, FastDiv divW, PoolGeo pool) {
     constexpr int EPL = 16;                         // elements per lane held in registers between the two passes
     __shared__ double s_da[256 / G];
     const int tid = threadIdx.x, sub = tid % G;
@@ -2145,11 +2181,53 @@ __global__ __launch_bounds__(256) void k_in_prelu_bwd(const float* __restrict__ 
     const float a = has_p ? prelu_a[prelu_span > 0 ? c / prelu_span : 0] : 1.f;
     float rc[EPL], rd[EPL];                         // centred value z - mean, d loss / d normalised value
     double s1 = 0.0, s2 = 0.0, sa = 0.0, sg = 0.0, sb = 0.0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pool_smem[];
+    const int poolQ = pool.k ? pool.Hp * pool.Wp : 0;
+    float* gbuf = (float*)pool_smem + (size_t)(tid / G) * HW;      // pool.lds: this plane's UN-POOLED upstream gradient, built in LDS
+    if (pool.k && pool.lds) {
+        // Scatter of the pooled gradient without atomics and in a fixed order: windows whose (row, column) indices agree modulo nc = ceil(k / s)
+        // are >= k apart and never share an element, so each of the nc^2 classes is a conflict-free pass of read-modify-writes; the classes run
+        // one after the other (a plane's G lanes sit in one wave, and LDS serves a wave's accesses in order).  The passes below then read gbuf[i].
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (the previous plane's reads of gbuf are done)
+        __builtin_amdgcn_wave_barrier();
+        if (act) for (int i = sub; i < HW; i += G) gbuf[i] = 0.f;
+        const int nc = pool.nc;
+        for (int cls = 0; cls < nc * nc; ++cls) {
+            const int ch = cls / nc, cw = cls - ch * nc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (act) for (int q = sub; q < poolQ; q += G) {
+                const int hp = fastdiv(q, pool.divWp), wp = q - hp * pool.Wp;
+                if (hp - fastdiv(hp, pool.divNc) * nc != ch || wp - fastdiv(wp, pool.divNc) * nc != cw) continue;
+                const int arg = pidx[(size_t)plane * poolQ + q], dh = fastdiv(arg, pool.divK), dw = arg - dh * pool.k;
+                gbuf[(hp * pool.s + dh) * W + wp * pool.s + dw] += dy[(size_t)plane * poolQ + q];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
     // upstream gradient of element i: plain, or through the fused MaxPool2d(2, 2) -- dy is then the dense pooled gradient and
     // only the element the forward marked in pidx receives it
     auto gy = [&](int i) -> float {
         if (!pidx) return dy[base + i];
+        if (pool.k && pool.lds) return gbuf[i];
         const int h = fastdiv(i, divW), w = i - h * W;
+        if (pool.k) {                                  // general MaxPool2d(k, s), plane too large for LDS: every window holding (h, w) whose maximum this element was
+            const int k = pool.k, st = pool.s;
+            const int hp1 = min(fastdiv(h, pool.divS), pool.Hp - 1), wp1 = min(fastdiv(w, pool.divS), pool.Wp - 1);
+            const int hp0 = h >= k ? fastdiv(h - k + st, pool.divS) : 0, wp0 = w >= k ? fastdiv(w - k + st, pool.divS) : 0;
+            float gsum = 0.f;
+            for (int hp = hp0; hp <= hp1; ++hp)
+                for (int wp = wp0; wp <= wp1; ++wp) {
+                    const int dh = h - hp * st, dw = w - wp * st;
+                    if (dh >= k || dw >= k) continue;
+                    const size_t pq = (size_t)plane * poolQ + (size_t)(hp * pool.Wp + wp);
+                    if (pidx[pq] == (unsigned char)(dh * k + dw)) gsum += dy[pq];
+                }
+            return gsum;
+        }
         const size_t pq = (size_t)plane * (HW >> 2) + (size_t)((h >> 1) * (W >> 1) + (w >> 1));
         return pidx[pq] == (unsigned char)((h & 1) * 2 + (w & 1)) ? dy[pq] : 0.f;
     };
@@ -2885,21 +2963,25 @@ PackGeo pack_geo(const KanGeom* g, const KanBasis* b, const KanPlan& pl, bool fl
 template <int G>
 void launch_in_fwd(hipStream_t st, int planes, const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma,
                    const float* beta, const float* a, float* y, float* mean, float* rstd, int Cn, int HW, long long bs, float eps, int span,
-                   unsigned char* pidx = nullptr, int W = 0) {
+                   unsigned char* pidx = nullptr, int W = 0, PoolGeo pg = PoolGeo{}) {
     int ppb = 256 / G;
-    hipLaunchKernelGGL((k_in_prelu_fwd<G>), dim3(ceil_div(planes, ppb)), dim3(256), 0, st, z, n_slabs, slab_elems, z_out, gamma, beta, a, y,
-                       mean, rstd, planes, Cn, HW, bs, eps, span, pidx, W, make_fastdiv(W > 1 ? W / 2 : 1));
+    size_t lds = 0;
+    if (pg.k) { lds = (size_t)ppb * HW * 4; pg.lds = lds <= 48 * 1024; if (!pg.lds) lds = 0; }
+    hipLaunchKernelGGL((k_in_prelu_fwd<G>), dim3(ceil_div(planes, ppb)), dim3(256), lds, st, z, n_slabs, slab_elems, z_out, gamma, beta, a, y,
+                       mean, rstd, planes, Cn, HW, bs, eps, span, pidx, W, make_fastdiv(W > 1 ? W / 2 : 1), pg);
 }
 template <int G>
 void launch_in_bwd(hipStream_t st, int planes, const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                    const float* beta, const float* a, float* dz, float* dgamma, float* dbeta, float* dprelu, int Cn, int HW, long long bs,
-                   int span, const unsigned char* pidx = nullptr, int W = 0) {
+                   int span, const unsigned char* pidx = nullptr, int W = 0, PoolGeo pg = PoolGeo{}) {
     int ppb = 256 / G;
     int blocks = ceil_div(planes, ppb);
     const int cap = (long long)planes * HW < (4ll << 20) ? 512 : 2048;       // small tensors: fewer same-address atomics on dprelu
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), 0, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
-                       dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, make_fastdiv(W > 0 ? W : 1));
+    size_t lds = 0;
+    if (pg.k) { lds = (size_t)ppb * HW * 4; pg.lds = lds <= 48 * 1024; if (!pg.lds) lds = 0; }
+    hipLaunchKernelGGL((k_in_prelu_bwd<G>), dim3(blocks), dim3(256), lds, st, dy, z, mean, rstd, gamma, beta, a, dz, dgamma,
+                       dbeta, dprelu, planes, Cn, HW, bs, span, pidx, W, make_fastdiv(W > 0 ? W : 1), pg);
 }
 template <int G, int EPL, int PPI, bool POOL>
 void launch_in_fwd_regs(hipStream_t st, int planes, const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma,
@@ -3525,12 +3607,12 @@ int kan_slab_reduce(const float* slabs, int n_slabs, long long slab_elems, float
 
 static int instnorm_fwd_any(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
                             const float* prelu_a, float* y, float* mean, float* rstd, int B, int Cn, int HW, long long bstride, float eps,
-                            int prelu_span, unsigned char* pidx, int W, void* stream) {
+                            int prelu_span, unsigned char* pidx, int W, void* stream, PoolGeo pg = PoolGeo{}) {
     if (!z || !z_out || !y || !mean || !rstd || n_slabs < 1 || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_fwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
 #define KAN_INF(G, EPL, PPI, POOL) launch_in_fwd_regs<G, EPL, PPI, POOL>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W)
-    if (pidx && HW <= 1024 && ((bstride | HW) & 1) == 0 && (((size_t)z | (size_t)z_out) & 7) == 0 && (slab_elems & 1) == 0) {   // lanes own 2x2 windows (float2 accesses)
+    if (pidx && !pg.k && HW <= 1024 && ((bstride | HW) & 1) == 0 && (((size_t)z | (size_t)z_out) & 7) == 0 && (slab_elems & 1) == 0) {   // lanes own 2x2 windows (float2 accesses)
         const int nwin = HW / 4;
         if (nwin <= 4) KAN_INF(4, 4, 2, true);
         else if (nwin <= 8) KAN_INF(8, 4, 2, true);
@@ -3554,12 +3636,12 @@ static int instnorm_fwd_any(const float* z, int n_slabs, long long slab_elems, f
         return launch_ok("instnorm_fwd");
     }
 #undef KAN_INF
-    switch (group_lanes(HW)) {
-        case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
-        case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
-        case 16: launch_in_fwd<16>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
-        case 32: launch_in_fwd<32>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
-        default: launch_in_fwd<64>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W); break;
+    switch (pg.k ? group_lanes((HW + 11) / 12) : group_lanes(HW)) {      // (pooled launches: ~12 elements per lane, more planes per workgroup)
+        case 4:  launch_in_fwd<4>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W, pg); break;
+        case 8:  launch_in_fwd<8>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W, pg); break;
+        case 16: launch_in_fwd<16>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W, pg); break;
+        case 32: launch_in_fwd<32>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W, pg); break;
+        default: launch_in_fwd<64>(st, planes, z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y, mean, rstd, Cn, HW, bstride, eps, prelu_span, pidx, W, pg); break;
     }
     return launch_ok("instnorm_fwd");
 }
@@ -3581,11 +3663,11 @@ int kan_instnorm_prelu_pool_fwd(const float* z, int n_slabs, long long slab_elem
 
 static int instnorm_bwd_any(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma, const float* beta,
                             const float* prelu_a, float* dz, float* dgamma, float* dbeta, float* dprelu, int B, int Cn, int HW,
-                            long long bstride, int prelu_span, const unsigned char* pidx, int W, void* stream) {
+                            long long bstride, int prelu_span, const unsigned char* pidx, int W, void* stream, PoolGeo pg = PoolGeo{}) {
     if (!dy || !z || !mean || !rstd || !dz || B < 1 || Cn < 1 || HW < 1) return fail("bad instnorm_bwd arguments");
     hipStream_t st = (hipStream_t)stream;
     int planes = B * Cn;
-    if (HW <= 1024) {                                // register-resident variants: G lanes x EPL elements cover the plane
+    if (HW <= 1024 && !pg.k) {                                // register-resident variants: G lanes x EPL elements cover the plane
 #define KAN_INB(G, EPL, PPI) launch_in_bwd_regs<G, EPL, PPI>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W)
         if (HW <= 4) KAN_INB(4, 1, 4);
         else if (HW <= 8) KAN_INB(8, 1, 4);
@@ -3599,12 +3681,12 @@ static int instnorm_bwd_any(const float* dy, const float* z, const float* mean, 
 #undef KAN_INB
         return launch_ok("instnorm_bwd");
     }
-    switch (HW == 64 ? 16 : group_lanes(HW)) {      // 8x8 planes: 4 elements per lane (measured 52 -> 37 us on 256x256x8x8)
-        case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
-        case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
-        case 16: launch_in_bwd<16>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
-        case 32: launch_in_bwd<32>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
-        default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W); break;
+    switch (pg.k ? group_lanes((HW + 11) / 12) : HW == 64 ? 16 : group_lanes(HW)) {      // 8x8 planes: 4 elements per lane (measured 52 -> 37 us on 256x256x8x8)
+        case 4:  launch_in_bwd<4>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W, pg); break;
+        case 8:  launch_in_bwd<8>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W, pg); break;
+        case 16: launch_in_bwd<16>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W, pg); break;
+        case 32: launch_in_bwd<32>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W, pg); break;
+        default: launch_in_bwd<64>(st, planes, dy, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, Cn, HW, bstride, prelu_span, pidx, W, pg); break;
     }
     return launch_ok("instnorm_bwd");
 }
@@ -3621,6 +3703,34 @@ int kan_instnorm_prelu_pool_bwd(const float* dy_pooled, const unsigned char* poo
     if (!pool_idx || H < 2 || W < 2 || (H & 1) || (W & 1)) return fail("fused 2x2 max-pool needs even H and W and the forward's index buffer");
     return instnorm_bwd_any(dy_pooled, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, B, Cn, H * W, bstride, prelu_span,
                             pool_idx, W, stream);
+}
+
+static int pool_geo(int H, int W, int k, int st, PoolGeo* pg) {
+    if (k < 2 || k > 15 || st < 1 || st > k || H < k || W < k) return fail("fused max-pool: need 2 <= kernel <= 15, 1 <= stride <= kernel, plane >= kernel");
+    pg->k = k; pg->s = st; pg->Hp = (H - k) / st + 1; pg->Wp = (W - k) / st + 1;
+    pg->divWp = make_fastdiv(pg->Wp); pg->divS = make_fastdiv(st); pg->divK = make_fastdiv(k); pg->nc = (k + st - 1) / st; pg->divNc = make_fastdiv(pg->nc); pg->lds = 0;
+    return 0;
+}
+
+int kan_instnorm_prelu_poolk_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out, const float* gamma, const float* beta,
+                                 const float* prelu_a, float* y_pooled, unsigned char* pool_idx, float* mean, float* rstd, int B, int Cn,
+                                 int H, int W, long long bstride, float eps, int prelu_span, int pool_k, int pool_s, void* stream) {
+    PoolGeo pg;
+    if (!pool_idx) return fail("fused max-pool needs an index buffer");
+    if (pool_geo(H, W, pool_k, pool_s, &pg)) return -1;
+    return instnorm_fwd_any(z, n_slabs, slab_elems, z_out, gamma, beta, prelu_a, y_pooled, mean, rstd, B, Cn, H * W, bstride, eps, prelu_span,
+                            pool_idx, W, stream, pg);
+}
+
+int kan_instnorm_prelu_poolk_bwd(const float* dy_pooled, const unsigned char* pool_idx, const float* z, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const float* prelu_a, float* dz, float* dgamma, float* dbeta,
+                                 float* dprelu, int B, int Cn, int H, int W, long long bstride, int prelu_span, int pool_k, int pool_s,
+                                 void* stream) {
+    PoolGeo pg;
+    if (!pool_idx) return fail("fused max-pool needs the forward's index buffer");
+    if (pool_geo(H, W, pool_k, pool_s, &pg)) return -1;
+    return instnorm_bwd_any(dy_pooled, z, mean, rstd, gamma, beta, prelu_a, dz, dgamma, dbeta, dprelu, B, Cn, H * W, bstride, prelu_span,
+                            pool_idx, W, stream, pg);
 }
 
 int kan_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2, double eps,

@@ -62,6 +62,12 @@ def _host_applied(module: nn.Module) -> bool:
     return type(module) is not nn.GELU and type(module) not in _ACT_CODES
 
 
+def _unfused_pool(y, pool):
+    """max_pool2d for the `pool` argument of the layers' forward: True = (2, 2), or a (kernel, stride) pair."""
+    k, st = (2, 2) if pool is True else (int(pool[0]), int(pool[1]))
+    return F.max_pool2d(y, k, st)
+
+
 def _dropout2d(p: float, ndim: int = 2):
     if p <= 0:
         return None
@@ -295,9 +301,10 @@ class KANConvNDLayer(_HipLayer):
         y = _norm3d(self.layer_norm, self.prelus, z, self.output_dim_group)
         return self.dropout(y) if self.dropout is not None else y
 
-    def forward(self, x, pool: bool = False):
+    def forward(self, x, pool=False):
         """`pool=True` (not part of the reference signature; used by models/kan_vgg.py for a layer that is followed by
-        MaxPool2d(2, 2)) returns max_pool2d(layer(x), 2, 2) with the pooling done inside the InstanceNorm+PReLU kernels."""
+        MaxPool2d(2, 2)) returns max_pool2d(layer(x), 2, 2) with the pooling done inside the InstanceNorm+PReLU kernels;
+        `pool=(k, s)` likewise for a general MaxPool2d(k, s) without padding (models/kan_alexnet.py: (3, 2))."""
         if self.ndim == 3:
             if pool:
                 raise NotImplementedError("pool=True is a 2-D fusion")
@@ -311,20 +318,20 @@ class KANConvNDLayer(_HipLayer):
             y = self._norm_prelu(self._windowed_stage(xa, xb, wb, ws))
             if self.dropout is not None:
                 y = self.dropout(y)
-            return F.max_pool2d(y, 2, 2) if pool else y
+            return _unfused_pool(y, pool) if pool else y
         if xb is None and _fusable_instnorm(self.layer_norm) and all(p.numel() == 1 for p in prelus):
             gam, bet = self._norm_affine(self.layer_norm)
             if pool and self.ndim == 2 and self.dropout is None:
                 ho, wo = spec.out_hw(x.shape[2], x.shape[3])
-                if ho % 2 == 0 and wo % 2 == 0:
-                    return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
+                if pool is not True or (ho % 2 == 0 and wo % 2 == 0):
+                    return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=pool)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
             # other norm classes (e.g. BatchNorm2d) or a host-applied activation: HIP conv stage, then the un-fused tail
             y = self._norm_prelu(ops.kan_conv(spec, xa, xb, wb, ws))
         if self.dropout is not None:
             y = self.dropout(y)
-        return F.max_pool2d(y, 2, 2) if pool else y
+        return _unfused_pool(y, pool) if pool else y
 
 
 class KANConv3DLayer(KANConvNDLayer):
@@ -493,8 +500,12 @@ class ChebyKANConvNDLayer(_HipLayer):
     def conv_spec(self) -> ops.ConvSpec:
         return self._spec(**self._basis_kw())
 
-    def forward(self, x):
+    def forward(self, x, pool=False):
+        """`pool` (not part of the reference signature; models/kan_alexnet.py passes (3, 2) for a layer followed by MaxPool2d(3, 2)): True or a
+        (kernel, stride) pair -- returns max_pool2d(layer(x), kernel, stride) with the pooling done inside the InstanceNorm kernels."""
         if self.ndim == 3:
+            if pool:
+                raise NotImplementedError("pool is a 2-D fusion")
             z = conv3d_stage(self._basis_kw(), self.kernel_size, self.stride, self.padding, self.dilation, self.groups, x, None, [],
                              [m.weight for m in self.poly_conv])
             y = _norm3d(self.layer_norm, None, z, self.output_dim // self.groups)
@@ -502,6 +513,9 @@ class ChebyKANConvNDLayer(_HipLayer):
         spec = self.conv_spec()
         x = self._lift(x)
         wp = self._w(self.poly_conv)
+        if pool and self.ndim == 2 and self.dropout is None and _fusable_instnorm(self.layer_norm):
+            gam, bet = self._norm_affine(self.layer_norm)
+            return ops.kan_conv_in_prelu(spec, x, [], wp, gam, bet, None, eps=self.layer_norm[0].eps, pool=pool)
         if _fusable_instnorm(self.layer_norm):
             gam, bet = self._norm_affine(self.layer_norm)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, [], wp, gam, bet, None, eps=self.layer_norm[0].eps))
@@ -511,7 +525,7 @@ class ChebyKANConvNDLayer(_HipLayer):
             y = torch.cat([self.layer_norm[g](z[:, g * og:(g + 1) * og]) for g in range(self.groups)], dim=1)
         if self.dropout is not None:
             y = self.dropout(y)
-        return y
+        return _unfused_pool(y, pool) if pool else y
 
 
 class ChebyKANConv1DLayer(ChebyKANConvNDLayer):

@@ -29,7 +29,8 @@ import torch.nn as nn
 
 from .. import _lib as L
 from .. import ops
-from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm, _norm3d, conv3d_stage)
+from .conv_layers import (_HipLayer, _act_code, _check_groups, _dropout2d, _filter_norm_kwargs, _fusable_instnorm, _norm3d, _unfused_pool,
+                          conv3d_stage)
 from .conv_layers import _need_conv2d as _need_conv1d_or_2d
 
 
@@ -101,8 +102,8 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
         y = _norm3d(self.layer_norm, self.prelus, z, self.output_dim_group)
         return self.dropout(y) if self.dropout is not None else y
 
-    def forward(self, x, pool: bool = False):
-        """`pool=True`: max_pool2d(layer(x), 2, 2) with the pooling inside the InstanceNorm+PReLU kernels (see KANConvNDLayer)."""
+    def forward(self, x, pool=False):
+        """`pool` = True or (kernel, stride): max_pool2d(layer(x), ...) with the pooling inside the InstanceNorm+PReLU kernels (see KANConvNDLayer)."""
         if self.ndim == 3:
             if pool:
                 raise NotImplementedError("pool=True is a 2-D fusion")
@@ -116,14 +117,14 @@ class _RecurrenceKANConvNDLayer(_HipLayer):
             gam, bet = self._norm_affine(self.layer_norm)
             if pool and self.dropout is None and self.ndim == 2:
                 ho, wo = spec.out_hw(x.shape[2], x.shape[3])
-                if ho % 2 == 0 and wo % 2 == 0:
-                    return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=True)
+                if pool is not True or (ho % 2 == 0 and wo % 2 == 0):
+                    return ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps, pool=pool)
             y = self._lower(ops.kan_conv_in_prelu(spec, x, wb, ws, gam, bet, prelus, eps=self.layer_norm[0].eps))
         else:
             y = self._norm_prelu(ops.kan_conv(spec, xa, xb, wb, ws))
         if self.dropout is not None:
             y = self.dropout(y)
-        return torch.nn.functional.max_pool2d(y, 2, 2) if pool else y
+        return _unfused_pool(y, pool) if pool else y
 
 
 # ------------------------------------------------------------------------------------------- Bessel

@@ -1,5 +1,6 @@
 """KAN-AlexNet caller (counterpart of the reference's models/kan_alexnet.py:10-313): plain FC head ('Linear' / 'AlexNet') or the
 reference's 'KAN' head -- two Linear+ReLU stages and a B-spline MLP KAN as the last stage (`kan_fc3`, kan_alexnet.py:151-167,184-199)."""
+import os
 from functools import partial
 from inspect import signature
 from typing import Any, Callable, List, Optional
@@ -7,6 +8,8 @@ from typing import Any, Callable, List, Optional
 import torch
 import torch.nn as nn
 
+from ..layers.conv_layers import ChebyKANConvNDLayer, KANConvNDLayer
+from ..layers.poly_layers import _RecurrenceKANConvNDLayer
 from ..layers.kan_conv import CONV_KAN_FACTORY
 from ..layers.mlp_layers import MLP_KAN_FACTORY
 
@@ -41,6 +44,7 @@ class AlexNetKAN(nn.Module):
             block(384, 256, kernel_size=3, padding=1, groups=groups),
             block(256, 256, kernel_size=3, padding=1, groups=groups), nn.MaxPool2d(kernel_size=3, stride=2))
         self.avgpool = nn.AdaptiveAvgPool2d((6, 6))
+        self.fuse_pool = os.environ.get("KAN_FUSE_POOL", "1") != "0"      # plain attribute: set False for the unfused sequence
         hid = 4096 if arch == "default" else 1024
         p = dropout if classifier_dropout is None else classifier_dropout
         if classifier_type == "KAN":
@@ -76,9 +80,38 @@ class AlexNetKAN(nn.Module):
                 nn.init.normal_(m.weight, 0, 0.01)
                 nn.init.constant_(m.bias, 0)
 
+    def forward_features(self, x):
+        """kan_alexnet.py:228 `self.features(x)`, with one fusion: a B-spline / ChebyKAN / recurrence-family layer directly followed by a plain
+        MaxPool2d(k, s) (here (3, 2)) runs the pooling inside its InstanceNorm(+PReLU) kernels -- the un-pooled activation and its gradient never
+        go through HBM and torch's two pooling kernels disappear.  Same values as the two modules in sequence (tests/test_gpu_models.py)."""
+        mods = list(self.features)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            ks = _plain_pool(nxt) if (self.fuse_pool and isinstance(nxt, nn.MaxPool2d)) else None
+            if ks is not None and isinstance(m, (KANConvNDLayer, ChebyKANConvNDLayer, _RecurrenceKANConvNDLayer)) and getattr(m, "ndim", 2) == 2:
+                x = m(x, pool=ks)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        x = self.avgpool(self.features(x))
+        x = self.avgpool(self.forward_features(x))
         return self.classifier(torch.flatten(x, 1))
+
+
+def _plain_pool(m: nn.MaxPool2d):
+    """(kernel, stride) of a square, unpadded, undilated floor-mode MaxPool2d the norm kernels can fuse, else None."""
+    sq = lambda v: (v if isinstance(v, int) else v[0] if (len(v) == 2 and v[0] == v[1]) else None)
+    k, st = sq(m.kernel_size), sq(m.stride if m.stride is not None else m.kernel_size)
+    zero = m.padding == 0 or m.padding == (0, 0)
+    one = m.dilation == 1 or m.dilation == (1, 1)
+    if k is None or st is None or not zero or not one or m.ceil_mode or m.return_indices or not (2 <= k <= 15 and 1 <= st <= k):
+        return None
+    return (k, st)
 
 
 def alexnet_kan(num_classes: int = 1000, input_channels: int = 3, dropout: float = 0.5, arch: str = "default",

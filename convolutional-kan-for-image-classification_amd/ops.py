@@ -610,7 +610,19 @@ class _KanConvInPrelu(torch.autograd.Function):
             # that the S-slab buffer can be freed (was: summed in place into slab 0, then cloned out of the buffer)
             z = zs[0] if S == 1 else torch.empty((B, Ot, Ho, Wo), device=x.device, dtype=torch.float32)
             pidx = None
-            if pool:                                     # MaxPool2d(2, 2) fused behind the PReLU: the full-size y is never written
+            if pool and pool is not True and tuple(pool) == (2, 2) and Ho % 2 == 0 and Wo % 2 == 0:
+                pool = True                              # even planes: the register-resident 2x2 kernels
+            if pool and pool is not True:                # MaxPool2d(k, s), overlapping windows (the AlexNet pattern 3, 2): generic norm kernels
+                pk, ps = pool
+                if Ho < pk or Wo < pk:
+                    raise L.KanConvError(f"fused {pk}x{pk} max-pool on a {Ho}x{Wo} plane")
+                Hp, Wp = (Ho - pk) // ps + 1, (Wo - pk) // ps + 1
+                y = torch.empty((B, Ot, Hp, Wp), device=x.device, dtype=torch.float32)
+                pidx = torch.empty((B, Ot, Hp, Wp), device=x.device, dtype=torch.uint8)
+                L.check(lib.kan_instnorm_prelu_poolk_fwd(_ptr(zs), S, plan.fwd_slab_elems, _ptr(z), _ptr(gamma), _ptr(beta), _ptr(slope),
+                                                         _ptr(y), C.c_void_p(pidx.data_ptr()), _ptr(mean), _ptr(rstd), B, Ot, Ho, Wo,
+                                                         Ot * HW, eps, Og if G > 1 else 0, pk, ps, _stream(x)), "kan_instnorm_prelu_poolk_fwd")
+            elif pool:                                   # MaxPool2d(2, 2) fused behind the PReLU: the full-size y is never written
                 if Ho % 2 or Wo % 2:
                     raise L.KanConvError(f"fused 2x2 max-pool needs an even plane, got {Ho}x{Wo}")
                 y = torch.empty((B, Ot, Ho // 2, Wo // 2), device=x.device, dtype=torch.float32)
@@ -654,7 +666,11 @@ class _KanConvInPrelu(torch.autograd.Function):
             dgam = torch.zeros_like(gamma) if use_affine else None
             dbet = torch.zeros_like(beta) if use_affine else None
             dpre = torch.zeros_like(slope) if use_prelu else None
-            if pool:
+            if pool and pool is not True:
+                L.check(lib.kan_instnorm_prelu_poolk_bwd(_ptr(dy), C.c_void_p(pidx.data_ptr()), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                                         _ptr(beta), _ptr(slope), _ptr(dz), _ptr(dgam), _ptr(dbet), _ptr(dpre), B, Ot, Ho, Wo,
+                                                         Ot * HW, Og if G > 1 else 0, pool[0], pool[1], _stream(x)), "kan_instnorm_prelu_poolk_bwd")
+            elif pool:
                 L.check(lib.kan_instnorm_prelu_pool_bwd(_ptr(dy), C.c_void_p(pidx.data_ptr()), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                                         _ptr(beta), _ptr(slope), _ptr(dz), _ptr(dgam), _ptr(dbet), _ptr(dpre), B, Ot, Ho, Wo,
                                                         Ot * HW, Og if G > 1 else 0, _stream(x)), "kan_instnorm_prelu_pool_bwd")
@@ -808,17 +824,29 @@ def kan_conv_phased(spec: ConvSpec, x: torch.Tensor, phases: torch.Tensor, w_bas
     return _KanConvPhased.apply(spec, x, xn, phases, *ws)
 
 
+def _norm_pool(pool):
+    """False | True (= the even-plane 2x2 kernels) | (k, s)."""
+    if pool is True or not pool:
+        return bool(pool)
+    k, st = int(pool[0]), int(pool[1])
+    if not (2 <= k <= 15 and 1 <= st <= k):
+        raise L.KanConvError(f"fused max-pool takes 2 <= kernel <= 15 and 1 <= stride <= kernel, got {pool!r}")
+    return (k, st)
+
+
 def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Tensor], w_basis: Sequence[torch.Tensor],
                       gammas: Optional[Sequence[torch.Tensor]], betas: Optional[Sequence[torch.Tensor]],
-                      prelus: Optional[Sequence[torch.Tensor]], eps: float = 1e-5, pool: bool = False) -> torch.Tensor:
-    """`pool=True` additionally applies MaxPool2d(kernel 2, stride 2) inside the same kernels (even output planes only)."""
+                      prelus: Optional[Sequence[torch.Tensor]], eps: float = 1e-5, pool=False) -> torch.Tensor:
+    """`pool=True` additionally applies MaxPool2d(kernel 2, stride 2) inside the same kernels (even output planes only); `pool=(k, s)` a general
+    MaxPool2d(k, s) without padding (overlapping windows allowed: the AlexNet pattern (3, 2))."""
+    pool = _norm_pool(pool)
     ws = (list(w_base) if spec.has_base else []) + list(w_basis)
     aff = gammas is not None
     extra = (list(gammas) + list(betas) if aff else []) + (list(prelus) if prelus is not None else [])
     n = _image_runs(spec, x, sum(w.shape[0] for w in w_basis))
     if n is not None:
-        return _by_image_runs(lambda a, _: _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), a, *ws, *extra), n, x)
-    return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, bool(pool), x, *ws, *extra)
+        return _by_image_runs(lambda a, _: _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, pool, a, *ws, *extra), n, x)
+    return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, pool, x, *ws, *extra)
 
 
 def instance_norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None, eps: float = 1e-5):

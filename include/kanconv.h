@@ -251,6 +251,19 @@ int kan_instnorm_prelu_pool_bwd(const float* dy_pooled, const unsigned char* poo
                                 float* dz, float* dgamma, float* dbeta, float* dprelu,
                                 int B, int Cn, int H, int W, long long bstride, int prelu_span, void* stream);
 
+/* The same with a general MaxPool2d(pool_k, pool_s) (no padding, floor mode; 2 <= pool_k <= 15, 1 <= pool_s <= pool_k) -- the AlexNet pattern
+ * MaxPool2d(kernel_size=3, stride=2) right after a layer (models/kan_alexnet.py:120-126 `features`).  y_pooled / dy_pooled / pool_idx are dense
+ * [B][Cn][Hp][Wp], Hp = (H - pool_k) / pool_s + 1; pool_idx = dh * pool_k + dw of the window's maximum (torch's rule, as above).  Windows overlap:
+ * the backward of an element sums the pooled gradients of every window that picked it, as torch's max_pool2d backward does. */
+int kan_instnorm_prelu_poolk_fwd(const float* z, int n_slabs, long long slab_elems, float* z_out,
+                                 const float* gamma, const float* beta, const float* prelu_a,
+                                 float* y_pooled, unsigned char* pool_idx, float* mean, float* rstd,
+                                 int B, int Cn, int H, int W, long long bstride, float eps, int prelu_span, int pool_k, int pool_s, void* stream);
+int kan_instnorm_prelu_poolk_bwd(const float* dy_pooled, const unsigned char* pool_idx, const float* z, const float* mean, const float* rstd,
+                                 const float* gamma, const float* beta, const float* prelu_a,
+                                 float* dz, float* dgamma, float* dbeta, float* dprelu,
+                                 int B, int Cn, int H, int W, long long bstride, int prelu_span, int pool_k, int pool_s, void* stream);
+
 /* One AdamW step over a flat fp32 block of n elements, in place (p, m = exp_avg, v = exp_avg_sq; g is read only and
  * multiplied by grad_scale first).  Replaces the per-tensor update loop of torch.optim.AdamW as the reference builds it
  * (generic_train.py:24 `optim.AdamW(model.parameters(), lr, weight_decay)`, stepped once per batch: evaluations.py train()),

@@ -385,3 +385,14 @@ def test_plane_windows_cover_every_basis_of_a_wide_grid():
             assert spec.has_base == has_base                         # (base_activation=None is Identity: still a base branch, kan_layers.py:132)
         if n + 1 <= L.KAN_MAX_PLANES:
             assert len(wins) == 1
+
+
+def test_alexnet_plain_pool_detection():
+    """models/kan_alexnet.py fuses only square, unpadded, undilated floor-mode pools (the reference's MaxPool2d(kernel_size=3, stride=2), kan_alexnet.py:120-126)."""
+    import torch.nn as nn
+    from convkan_amd.models.kan_alexnet import _plain_pool
+    assert _plain_pool(nn.MaxPool2d(kernel_size=3, stride=2)) == (3, 2)
+    assert _plain_pool(nn.MaxPool2d(2)) == (2, 2) and _plain_pool(nn.MaxPool2d((3, 3), (1, 1))) == (3, 1)
+    for bad in (nn.MaxPool2d(3, 2, padding=1), nn.MaxPool2d(3, 2, ceil_mode=True), nn.MaxPool2d((3, 2), 2), nn.MaxPool2d(3, 2, dilation=2),
+                nn.MaxPool2d(2, 3), nn.MaxPool2d(3, 2, return_indices=True)):
+        assert _plain_pool(bad) is None

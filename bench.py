@@ -314,6 +314,41 @@ def other_workload(name, device, steps, warmup):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def split_precision_forward(device, iters: int = 20):
+    """OPT-IN mode, reported apart from everything else (`dtype` f32 above is the exact path and stays the default and the headline): the split-precision
+    forward of the 256 -> 256 @ 8x8 layer (3 x bf16 pieces, six bf16 MFMA products per k-block; kanconv.h kan_conv_fwd_split) next to the exact kernel of the
+    same layer, same inputs; `max_diff_vs_exact` is max |z_split - z_exact| / max |z_exact| (tests/test_gpu_split.py holds the fp64 comparison)."""
+    import torch
+    try:
+        import convkan_amd as K
+        from convkan_amd import ops
+        torch.manual_seed(0)
+        layer = K.KANConv2DLayer(256, 256, 3, padding=1, base_activation=torch.nn.SiLU).to(device)      # KAN-VGG11's layer 4 (models/kan_vgg.py)
+        x = torch.randn(256, 256, 8, 8, device=device)
+        spec, wb, ws = layer.conv_spec(), layer.base_conv[0].weight.detach(), layer.spline_conv[0].weight.detach()
+        z_s, wc = ops.kan_conv_fwd_split(spec, x, wb, ws)
+        z_e = ops.kan_conv(spec, x, None, [wb], [ws])
+        diff = float((z_s - z_e).abs().max() / z_e.abs().max())
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters
+        ms_s = timed(lambda: ops.kan_conv_fwd_split(spec, x, wb, ws, wc))
+        ms_e = timed(lambda: ops.kan_conv(spec, x, None, [wb], [ws]))
+        gf = 2.0 * 256 * 64 * 256 * 256 * 81 / 1e9
+        return {"workload": "conv stage forward of KANConv2DLayer 256->256 @ 8x8, bs 256 (opt-in split-precision mode vs the exact fp32 kernel incl. its slab sum)",
+                "split_ms": round(ms_s, 4), "exact_ms": round(ms_e, 4), "split_tflops_fp32_equivalent": round(gf / ms_s, 1), "exact_tflops": round(gf / ms_e, 1),
+                "speedup": round(ms_e / ms_s, 2), "max_diff_vs_exact": diff, "default": False}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 # --------------------------------------------------------------------------------------------------- multi-rank launch
 def kfd_gpu_count():
     """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs; CPUs have simd_count 0), cut to the
@@ -478,7 +513,8 @@ def main():
             del model, x, t
             torch.cuda.empty_cache()
             out["other_workloads"] = {"fastkan_layer": other_workload("fastkan_layer", device, 30, 10),
-                                      "cheby_alexnet": other_workload("cheby_alexnet", device, 10, 3)}
+                                      "cheby_alexnet": other_workload("cheby_alexnet", device, 10, 3),
+                                      "split_precision_forward": split_precision_forward(device)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters, args.cpu_warmup)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)

@@ -71,6 +71,10 @@ SIGNATURES = {
     "kan_instnorm_prelu_pool_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _I, _P]),
     "kan_instnorm_prelu_poolk_fwd": (_I, [_P, _I, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _F, _I, _I, _I, _P]),
     "kan_instnorm_prelu_poolk_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _LL, _I, _I, _I, _P]),
+    "kan_split_supported": (_I, [C.POINTER(KanGeom), C.POINTER(KanBasis)]),
+    "kan_split_weight_bytes": (_LL, [C.POINTER(KanGeom), C.POINTER(KanBasis)]),
+    "kan_split_pack_weights": (_I, [_P, _P, _P, C.POINTER(KanGeom), C.POINTER(KanBasis), _P]),
+    "kan_conv_fwd_split": (_I, [_P, _P, _P, C.POINTER(KanGeom), C.POINTER(KanBasis), _P]),
     "kan_wav_fwd": (_I, [_P, _P, _P, _P, _P, C.POINTER(KanWavGeom), _P]),
     "kan_wav_bwd_input": (_I, [_P, _P, _P, _P, _P, _P, C.POINTER(KanWavGeom), _P]),
     "kan_wav_param_workspace": (_LL, [C.POINTER(KanWavGeom)]),

@@ -849,5 +849,28 @@ def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Te
     return _KanConvInPrelu.apply(spec, float(eps), aff, prelus is not None, pool, x, *ws, *extra)
 
 
+def kan_conv_fwd_split(spec: ConvSpec, x: torch.Tensor, w_base: torch.Tensor, w_basis: torch.Tensor, wc: Optional[torch.Tensor] = None):
+    """OPT-IN split-precision conv stage (forward only, no autograd; kanconv.h `kan_conv_fwd_split`): the fp32 result of `kan_conv` to ~4e-6 of its largest
+    element, through 3 x bf16 pieces and six bf16 MFMA products per k-block.  Never used by the layers; scope: default B-spline spec on 8x8 planes, 3x3 /
+    stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even batch (raises KanConvError otherwise).  Returns (z, wc): pass `wc` back while the
+    weights are unchanged to skip the cut (0.05 ms at 256 -> 256)."""
+    lib = L.load()
+    x, w_base, w_basis = _require(x, "x"), _require(w_base, "w_base"), _require(w_basis, "w_basis")
+    B, Ct, H, W = x.shape
+    Ot = w_basis.shape[0]
+    geom, basis, _ = _plan_cached(spec, B, Ct, H, W, Ot, Ct, Ot)
+    if not lib.kan_split_supported(C.byref(geom), C.byref(basis)):
+        raise L.KanConvError("split-precision forward: default B-spline spec (grid 5, order 3, SiLU base branch), 8x8 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, "
+                             "even batch only")
+    with torch.cuda.device(x.device):
+        if wc is None:
+            wc = torch.empty(lib.kan_split_weight_bytes(C.byref(geom), C.byref(basis)), device=x.device, dtype=torch.uint8)
+            L.check(lib.kan_split_pack_weights(_ptr(w_base), _ptr(w_basis), C.c_void_p(wc.data_ptr()), C.byref(geom), C.byref(basis), _stream(x)),
+                    "kan_split_pack_weights")
+        z = torch.empty((B, Ot, H, W), device=x.device, dtype=torch.float32)
+        L.check(lib.kan_conv_fwd_split(_ptr(x), C.c_void_p(wc.data_ptr()), _ptr(z), C.byref(geom), C.byref(basis), _stream(x)), "kan_conv_fwd_split")
+    return z, wc
+
+
 def instance_norm(x: torch.Tensor, gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None, eps: float = 1e-5):
     return _InstanceNorm.apply(x, gamma, beta, float(eps))

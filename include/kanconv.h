@@ -264,6 +264,20 @@ int kan_instnorm_prelu_poolk_bwd(const float* dy_pooled, const unsigned char* po
                                  float* dz, float* dgamma, float* dbeta, float* dprelu,
                                  int B, int Cn, int H, int W, long long bstride, int prelu_span, int pool_k, int pool_s, void* stream);
 
+/* OPT-IN split-precision forward: NOT reached from kan_conv_fwd, never the default.  Every fp32 operand is cut into three bf16
+ * pieces (hi + mid + lo = 24 mantissa bits) and six bf16 MFMA products per 16-deep block are accumulated in fp32: the fp32 result to ~4e-6 of its
+ * largest element at K = 20 736 (one fp32 accumulation chain; the exact path sits at ~1e-6), at ~1.7x the speed of the exact fp32 MFMA kernel.
+ * Scope: the default B-spline spec (n_basis 8, order 3, SiLU) on 8x8 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even B, dense NCHW
+ * -- KAN-VGG11's 128 -> 256 and 256 -> 256 layers.  Computes what kan_conv_fwd computes for such a layer (kan_layers.py:199-200, 203-239) into ONE slab.
+ *   kan_split_supported      1 if (geom, basis) is in scope
+ *   kan_split_weight_bytes   size of the cut-weight buffer `wc` (0 if out of scope)
+ *   kan_split_pack_weights   reference-layout weights (as kan_pack_weights takes them) -> wc; once per weight update
+ *   kan_conv_fwd_split       z[B][O][8][8] = the conv stage */
+int kan_split_supported(const KanGeom* geom, const KanBasis* basis);
+long long kan_split_weight_bytes(const KanGeom* geom, const KanBasis* basis);
+int kan_split_pack_weights(const float* w_base, const float* w_basis, void* wc, const KanGeom* geom, const KanBasis* basis, void* stream);
+int kan_conv_fwd_split(const float* x, const void* wc, float* z, const KanGeom* geom, const KanBasis* basis, void* stream);
+
 /* One AdamW step over a flat fp32 block of n elements, in place (p, m = exp_avg, v = exp_avg_sq; g is read only and
  * multiplied by grad_scale first).  Replaces the per-tensor update loop of torch.optim.AdamW as the reference builds it
  * (generic_train.py:24 `optim.AdamW(model.parameters(), lr, weight_decay)`, stepped once per batch: evaluations.py train()),

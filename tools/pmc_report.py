@@ -13,7 +13,7 @@ def load(d):
     per = collections.defaultdict(lambda: collections.defaultdict(list))
     for fn in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(fn)):
-            m = re.search(r"(k_conv_[a-z_]+(?:<[^>]*>)?)", r["Kernel_Name"])
+            m = re.search(r"(k_(?:conv|band)_[a-z_]+(?:<[^>]*>)?)", r["Kernel_Name"])
             if not m:
                 continue
             k = m.group(1)

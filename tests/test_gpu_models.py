@@ -461,3 +461,18 @@ def test_fused_adamw_reads_gradients_from_reducer_buckets(gpu_lib):
             assert err <= (1e-6 if p.dim() == 4 else 1e-4), (n, err)          # PReLU slopes: float atomics upstream
     finally:
         red.remove()
+
+
+def test_fastkan_layer_step_replays_as_hip_graph(gpu_lib):
+    """BASELINE.json configs[1] is launch-bound in eager mode (0.24 ms of kernels in a 0.43-0.48 ms step): the whole step -- every launch goes through ctypes
+    onto torch's current stream -- must be capturable into ONE HIP graph and replay bit-identically (bench.py reports its replay time under
+    other_workloads.fastkan_layer.hip_graph)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    bench._load_torch()
+    dev = torch.device("cuda:0")
+    model = bench.build_model(dev, "fastkan_layer")
+    x = torch.randn(256, 3, 32, 32, device=dev)
+    res = bench.hip_graph_replay(model, x, None, iters=5)
+    assert res.get("matches_eager_bitwise") is True, res

@@ -341,7 +341,10 @@ def other_workload(name, device, steps, warmup):
         if name == "fastkan_layer":                       # launch-bound: the same step as one HIP graph
             out["hip_graph"] = hip_graph_replay(model, x, t)
             if "ms_per_step" in out["hip_graph"]:
-                out["hip_graph"]["images_per_sec"] = round(wl["batch"] / out["hip_graph"]["ms_per_step"] * 1e3, 1)
+                gips = wl["batch"] / out["hip_graph"]["ms_per_step"] * 1e3
+                out["hip_graph"]["images_per_sec"] = round(gips, 1)
+                out["hip_graph"]["end_to_end_frac"] = round(gips * wl["gflop_per_image"] / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4)    # as roofline.end_to_end_frac, on the replay time
+                out["hip_graph"]["end_to_end_executed_frac"] = round(roof["end_to_end_executed_frac"] * out["ms_per_step"] / out["hip_graph"]["ms_per_step"], 4)
         del model, x, t, prof
         torch.cuda.empty_cache()
         return out

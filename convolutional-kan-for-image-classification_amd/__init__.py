@@ -17,7 +17,7 @@ from .layers.conv_layers import KANConv1DLayer, FastKANConv1DLayer, ChebyKANConv
 from .layers.relu_layers import ReLUConvNDLayer, ReLUKANConv2DLayer, ReLUKANConv1DLayer   # noqa: F401,E402
 from .layers.kan_conv import relukan_conv   # noqa: F401,E402
 from .optim import FusedAdamW   # noqa: F401,E402
-from .train import train_step, train_model_generic   # noqa: F401,E402
+from .train import GraphedStep, train_step, train_model_generic   # noqa: F401,E402
 from .layers.gram_layers import GRAMKANConvNDLayer, GRAMKANConv2DLayer   # noqa: F401,E402
 from .layers.kan_conv import gramkan_conv   # noqa: F401,E402
 from .layers.conv_layers import KANConv3DLayer, FastKANConv3DLayer, ChebyKANConv3DLayer   # noqa: F401,E402

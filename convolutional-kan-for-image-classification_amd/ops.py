@@ -15,6 +15,7 @@ the per-group weights are stacked once per call, activations are never copied or
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import weakref
@@ -230,6 +231,22 @@ _EPOCH = 0
 PACK_STATS = {"calls": 0, "forced": 0, "skipped": 0}  # host-side counters (tests, tools)
 
 
+_ALWAYS_PACK = False
+
+
+@contextlib.contextmanager
+def always_pack():
+    """Inside: every conv stage packs its weights unconditionally (the pack kernels are enqueued whatever the host-side stamps say).  For code that
+    RECORDS launches for later replay -- a HIP graph (`train.GraphedStep`): the decision "weights unchanged, skip the pack" is taken on the host at
+    record time and would be frozen into the graph, so a replay after an optimizer step would multiply stale layouts."""
+    global _ALWAYS_PACK
+    prev, _ALWAYS_PACK = _ALWAYS_PACK, True
+    try:
+        yield
+    finally:
+        _ALWAYS_PACK = prev
+
+
 def weights_changed() -> None:
     """Tell the packed-weight cache that weights may have been written through a path the version counters cannot see (`.data` ops,
     `dist.broadcast(p.data)`, raw-pointer kernels): every layer fingerprints its weights on its next call."""
@@ -298,7 +315,7 @@ def _pack(lib, spec, geom, basis, plan, plan_key, w_base, w_basis, need_dgrad, p
         return fresh()                                # plane-major weights): an entry would be built and dropped on every call
     ent = _packed_entry((_layout_key(spec, geom, plan), device.index) + tuple(id(o) for o in owners), owners)
     stamps = [(w.data_ptr(), o._version, tuple(w.shape)) for w, o in zip((w for w in (wb, ws) if w is not None), owners)]
-    force = ent.wp is None or ent.stamps != stamps or (need_dgrad and ent.wd is None)
+    force = _ALWAYS_PACK or ent.wp is None or ent.stamps != stamps or (need_dgrad and ent.wd is None)
     if ent.wp is None:
         ent.wp = torch.empty(plan.packed_weight_bytes // 4, device=device, dtype=torch.float32)
         ent.ring = torch.zeros(L.KAN_FP_WORDS, device=device, dtype=torch.int64)

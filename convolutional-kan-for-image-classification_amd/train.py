@@ -30,6 +30,56 @@ def train_step(model: nn.Module, data: torch.Tensor, target: torch.Tensor, optim
     return loss.detach()
 
 
+class GraphedStep:
+    """zero_grad / forward / loss / backward of ``model`` on fixed shapes, recorded ONCE into a HIP graph and replayed per batch.
+
+    Every launch of the hot path goes through ctypes onto torch's current stream, so ``torch.cuda.graph`` captures the conv-KAN kernels next to
+    torch's own; a replay costs one graph launch instead of the host's per-kernel work.  That pays where the step is launch-bound -- small models and
+    single layers (BASELINE config 2: 0.23 ms replayed against 0.43-0.48 ms eager, bit-identical); KAN-VGG11 at bs 256 keeps the GPU busy either way.
+    The weight packs are recorded unconditionally (``ops.always_pack``): the replay reads the weights as they are at replay time, so an optimizer may
+    update them in place between replays.  Keep the optimizer step OUTSIDE the graph (AdamW's bias correction takes the step count as a kernel
+    argument) and do not call ``zero_grad`` between replays: the recorded backward assigns ``p.grad`` (static tensors) rather than accumulating.
+
+        step = GraphedStep(model, example_data, example_target)
+        for data, target in batches:
+            loss = step(data, target)          # device-resident, overwritten by the next call
+            optimizer.step()
+    """
+
+    def __init__(self, model: nn.Module, example_data: torch.Tensor, example_target: torch.Tensor, criterion: Optional[nn.Module] = None,
+                 warmup: int = 3):
+        from . import ops
+        if not example_data.is_cuda:
+            raise ValueError("GraphedStep needs device tensors")
+        self.model = model
+        self.criterion = criterion if criterion is not None else nn.CrossEntropyLoss()
+        self.data, self.target = example_data.clone(), example_target.clone()
+        side = torch.cuda.Stream(device=example_data.device)
+        side.wait_stream(torch.cuda.current_stream(example_data.device))
+        with torch.cuda.stream(side):                      # warm-up off the capture stream: plans, workspaces, torch's lazy initialisations
+            for _ in range(max(1, warmup)):
+                self._eager()
+        torch.cuda.current_stream(example_data.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        self.model.zero_grad(set_to_none=True)             # recorded backward then ASSIGNS the gradients (tensors of the graph's pool)
+        with ops.always_pack(), torch.cuda.graph(self.graph):
+            self.loss = self._eager()
+
+    def _eager(self) -> torch.Tensor:
+        self.model.zero_grad(set_to_none=True)
+        loss = self.criterion(self.model(self.data), self.target)
+        loss.backward()
+        return loss.detach()
+
+    def __call__(self, data: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if data.shape != self.data.shape or target.shape != self.target.shape:
+            raise ValueError(f"GraphedStep was recorded for {tuple(self.data.shape)} / {tuple(self.target.shape)}, got {tuple(data.shape)} / {tuple(target.shape)}")
+        self.data.copy_(data, non_blocking=True)
+        self.target.copy_(target, non_blocking=True)
+        self.graph.replay()
+        return self.loss
+
+
 def train_model_generic(model: nn.Module, train_batches: Iterable[Tuple[torch.Tensor, torch.Tensor]], device="cuda",
                         learning_rate: float = 1e-3, weight_decay: float = 1e-4, gamma: float = 0.8, epochs: int = 15,
                         reducer=None) -> List[float]:

@@ -476,3 +476,36 @@ def test_fastkan_layer_step_replays_as_hip_graph(gpu_lib):
     x = torch.randn(256, 3, 32, 32, device=dev)
     res = bench.hip_graph_replay(model, x, None, iters=5)
     assert res.get("matches_eager_bitwise") is True, res
+
+
+@pytest.mark.parametrize("kind", ["KAN", "FastKAN", "ChebyKAN"])
+def test_graphed_training_steps_equal_eager_steps_bitwise(kind, gpu_lib):
+    """train.GraphedStep: forward + loss + backward recorded once into a HIP graph, FusedAdamW outside it.  Six training steps on changing batches must
+    leave exactly the weights and losses of six eager `train_step`s from the same initialisation -- in particular the recorded weight packs must read
+    the weights the optimizer wrote between replays (ops.always_pack), and the recorded backward must assign, not accumulate, the gradients."""
+    import copy
+    import convkan_amd as K
+    from convkan_amd.models import vggkan
+    torch.manual_seed(7)
+    base = vggkan(3, 10, arch="VGG11", kan_conv=kind, dropout_linear=0.0).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    batches = [(torch.randn(32, 3, 32, 32, device="cuda", generator=g), torch.randint(0, 10, (32,), device="cuda", generator=g)) for _ in range(6)]
+    out = {}
+    for mode in ("eager", "graph"):
+        model = copy.deepcopy(base)
+        opt = K.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-4)
+        losses = []
+        if mode == "eager":
+            for d, t in batches:
+                losses.append(float(K.train_step(model, d, t, opt)))
+        else:
+            step = K.GraphedStep(model, batches[0][0], batches[0][1])
+            for d, t in batches:
+                losses.append(float(step(d, t)))
+                opt.step()
+        torch.cuda.synchronize()
+        out[mode] = (losses, [p.detach().clone() for p in model.parameters()])
+    assert out["eager"][0] == out["graph"][0], (out["eager"][0], out["graph"][0])
+    for a, b in zip(out["eager"][1], out["graph"][1]):
+        assert torch.equal(a, b)
+    assert out["eager"][0][-1] != out["eager"][0][0]          # (the weights did move)

@@ -672,6 +672,35 @@ __global__ __launch_bounds__(WO * 2 * 64, ((WO > 2 && !(R * W == 16 && NIMG * W 
     }
 }
 
+// Sum M per-lane values over the 64 lanes of a wave, leaving value i's total in the lanes of group i (a reduce-scatter butterfly): at every step a
+// lane keeps one half of its values and receives its partner's copy of that half -- M / 2 + M / 4 + ... + 1 shuffles, then plain xor steps over the lanes
+// that hold the same index (M = 16: 8 + 4 + 2 + 1 + 1 + 1 = 17 shuffles against 16 x 6 for one butterfly per value).  On return lanes with equal
+// lane / (64 / M) hold `tot` = the total of value `idx`; fixed order, so the result is deterministic.
+template <int M>
+__device__ __forceinline__ void wave_reduce_scatter(float (&v)[M], int lane, int& idx, float& tot) {
+    int base = 0;
+    int m = M;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        if (m > 1) {
+            const int h = m / 2;
+            const bool up = (lane & off) != 0;
+#pragma unroll
+            for (int i = 0; i < M / 2; ++i) {
+                if (i < h) {
+                    const float keep = up ? v[h + i] : v[i], send = up ? v[i] : v[h + i];
+                    v[i] = keep + __shfl_xor(send, off, 64);
+                }
+            }
+            base += up ? h : 0;
+            m = h;
+        } else {
+            v[0] += __shfl_xor(v[0], off, 64);
+        }
+    }
+    idx = base; tot = v[0];
+}
+
 // ============================================================================ backward data
 // Tile: 128 rows = two halves of 64 rows, each holding CH = 64 / P whole channels x P planes (flat cl*P + p, rest
 // zero), x 128 input pixels.  Depth steps: (tap, 16 outputs); weights come from the wd layout (straight 16 x 128
@@ -1160,14 +1189,35 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_data(
                 if (c >= g.C) continue;
                 const float xb = pv ? (same_in ? x : xn)[(size_t)pb * g.xbs + (size_t)c * HW + (size_t)(ph_ * g.W + pw_)] : 0.f;      // the tensor the basis reads
                 const float* lo = bs.ctab + (size_t)c * 2 * nb;
-                for (int j = 0; j < nb; ++j) {
-                    const float gv = pv ? smem[(cl * P + hb + j) * TP + pxl] : 0.f;
-                    const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(lo[nb + j] - xb, 0.f);
-                    const float q2 = 2.0f * (x1 * x2 * rr) * rr;
-                    float vlo = -(q2 * x2) * gv, vhi = (q2 * x1) * gv;
+                // The 2 n products of the channel are summed over the wave by a reduce-scatter butterfly (wave_reduce_scatter: 17 shuffles for 16 values
+                // instead of 16 six-step reductions = 96), after which lane groups hold different sums and add them with ONE atomic each.
+                if (2 * nb <= 16) {
+                    float v[16];
 #pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) { vlo += __shfl_xor(vlo, off, 64); vhi += __shfl_xor(vhi, off, 64); }
-                    if (lane == 0) { atomicAdd(dpar + (size_t)c * 2 * nb + j, vlo); atomicAdd(dpar + (size_t)c * 2 * nb + nb + j, vhi); }
+                    for (int j = 0; j < 8; ++j) {
+                        float vlo = 0.f, vhi = 0.f;
+                        if (j < nb) {
+                            const float gv = pv ? smem[(cl * P + hb + j) * TP + pxl] : 0.f;
+                            const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(lo[nb + j] - xb, 0.f);
+                            const float q2 = 2.0f * (x1 * x2 * rr) * rr;
+                            vlo = -(q2 * x2) * gv; vhi = (q2 * x1) * gv;
+                        }
+                        v[j] = vlo; v[8 + j] = vhi;
+                    }
+                    int idx; float tot;
+                    wave_reduce_scatter<16>(v, lane, idx, tot);                    // idx < 8: lo[idx], else hi[idx - 8]
+                    const int j = idx & 7;
+                    if ((lane & 3) == 0 && j < nb) atomicAdd(dpar + (size_t)c * 2 * nb + (idx < 8 ? j : nb + j), tot);
+                } else {
+                    for (int j = 0; j < nb; ++j) {
+                        const float gv = pv ? smem[(cl * P + hb + j) * TP + pxl] : 0.f;
+                        const float x1 = fmaxf(xb - lo[j], 0.f), x2 = fmaxf(lo[nb + j] - xb, 0.f);
+                        const float q2 = 2.0f * (x1 * x2 * rr) * rr;
+                        float vlo = -(q2 * x2) * gv, vhi = (q2 * x1) * gv;
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) { vlo += __shfl_xor(vlo, off, 64); vhi += __shfl_xor(vhi, off, 64); }
+                        if (lane == 0) { atomicAdd(dpar + (size_t)c * 2 * nb + j, vlo); atomicAdd(dpar + (size_t)c * 2 * nb + nb + j, vhi); }
+                    }
                 }
             }
         }
@@ -2865,6 +2915,9 @@ int make_plan(const KanGeom* g, const KanBasis* b, KanPlan* pl) {
         const bool use18 = (long long)i18 * pl->P * 16 > (long long)i16 * pl->P * 18;   // i18*P/18 > i16*P/16
         pl->KC = use18 ? 18 : 16;
         pl->IPC = use18 ? i18 : i16;
+        // 10 - 12 planes (FourierKAN grid 5: P = 11) hold ONE item in either step and leave 31 - 44 % of the rows -- of the MFMA work -- as zero padding:
+        // a 12-row step wastes 0 - 17 % (round 3; the generic forward is the only kernel that pays for pad rows)
+        if (pl->P >= 10 && pl->P <= 12) { pl->KC = 12; pl->IPC = 1; }
         if (halo_fwd(g, b)) { pl->KC = 2 * pl->P; pl->IPC = 2; }      // pair order: one step = one tap of a channel pair, no pad rows
     }
     pl->Kpad = ceil_div(g->C * T, pl->IPC) * pl->KC;
@@ -3282,8 +3335,10 @@ int kan_conv_fwd(const float* x, const float* xn, const float* wp, float* z, con
 #define KAN_FWD_KIND(KIND)                                                     \
     do {                                                                       \
         if (c.TO == 128 && pl.KC == 18) KAN_FWD(KIND, 2, 2, 18);               \
+        else if (c.TO == 128 && pl.KC == 12) KAN_FWD(KIND, 2, 2, 12);          \
         else if (c.TO == 128) KAN_FWD(KIND, 2, 2, 16);                         \
         else if (pl.KC == 18) KAN_FWD(KIND, 1, 2, 18);                         \
+        else if (pl.KC == 12) KAN_FWD(KIND, 1, 2, 12);                         \
         else KAN_FWD(KIND, 1, 2, 16);                                          \
     } while (0)
     const int fast = fast_variant(b);

@@ -1,0 +1,4 @@
+# round 3, call W: 12-row forward steps for 10-12 planes (FourierKAN P = 11): parity of everything generic, family bench line
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && O=gpurun_out/r3w && rm -rf $O && mkdir -p $O &&
+(timeout -k 10 900 python -m pytest tests/test_gpu_golden.py tests/test_gpu_fuzz.py tests/test_gpu_oracle.py -q -m gpu > $O/tests.txt 2>&1 ; rc=$? ; echo "pytest rc $rc" ; tail -3 $O/tests.txt ; test $rc -eq 0) &&
+(timeout -k 10 300 python tools/family_bench.py FourierKAN ReLUKAN > $O/family.txt 2>&1 ; echo "rc $?"; tail -2 $O/family.txt)

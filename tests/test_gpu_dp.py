@@ -157,3 +157,42 @@ def test_bench_launches_its_own_ranks(gpu_lib):
     ar = doc["allreduce"]                                                # the N > 1 diagnostics (one untimed traced step, per-rank clocks)
     assert "trace_error" not in ar and ar["exposed_ms"] >= 0.0 and len(ar["bucket_trace"]) == ar["buckets"] >= 4
     assert all(b["end_ms"] >= b["ready_ms"] for b in ar["bucket_trace"]) and doc["ms_per_step_ranks"]["min"] <= doc["ms_per_step_ranks"]["max"]
+
+
+def test_two_ranks_on_one_gpu_average_conv_kan_gradients(gpu_lib, tmp_path):
+    """Two data-parallel ranks of KAN-VGG11 (32 images each) against ONE process on the 64 images: after `finish()` every rank holds the full-batch
+    gradient.  A 1-GPU lease has no second device for RCCL, so the two ranks share cuda:0 and exchange over gloo (tests/_dp_rank_gpu.py) -- everything
+    above one rank except the RCCL transport itself: hooks of conv-KAN layers arming buckets, gradient sinks under two concurrent processes, the
+    side-stream collective, the mean."""
+    import torch.nn.functional as F
+    from convkan_amd.models import vggkan
+    out = str(tmp_path / "grads")
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_rank_gpu.py"), out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    torch.manual_seed(3)
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", dropout_linear=0.0).cuda().train()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(64, 3, 32, 32, device="cuda", generator=g)
+    t = torch.randint(0, 10, (64,), device="cuda", generator=g)
+    # reference: the two shards one after the other in THIS process (the launch shapes of the ranks, hence their exact per-shard gradients), then the
+    # mean -- a single 64-image launch would differ at model level by the pool / PReLU re-routing of tests/test_gpu_models.py, not by the exchange
+    shard = []
+    for r in range(2):
+        m.zero_grad(set_to_none=True)
+        F.cross_entropy(m(x[r * 32:(r + 1) * 32]), t[r * 32:(r + 1) * 32]).backward()
+        torch.cuda.synchronize()
+        shard.append({n: p.grad.detach().clone() for n, p in m.named_parameters()})
+    ranks = [torch.load(f"{out}.rank{r}") for r in range(2)]
+    worst = 0.0
+    for n, _ in m.named_parameters():
+        ref = ((shard[0][n] + shard[1][n]) * 0.5).cpu()
+        assert torch.equal(ranks[0][n], ranks[1][n]), n                       # both ranks hold the same reduced gradient
+        worst = max(worst, float((ranks[0][n] - ref).abs().max() / (ref.abs().max() + 1e-30)))
+    assert worst <= 1e-5, worst                                               # sum over ranks, halved: the mean of the two shard gradients (measured 1.0e-6: the
+                                                                              # PReLU-slope and affine-norm gradients use float atomics, everything else is bit-equal)

@@ -49,3 +49,37 @@ def test_split_forward_scope_is_enforced(gpu_lib):
         layer = layer.cuda()
         with pytest.raises(L.KanConvError, match="split-precision"):
             ops.kan_conv_fwd_split(layer.conv_spec(), x.cuda(), layer.base_conv[0].weight.detach(), layer.spline_conv[0].weight.detach())
+
+
+def test_split_precision_inference_mode_on_kan_vgg11(gpu_lib):
+    """ops.split_precision_inference(): under no_grad the two 8x8 layers of KAN-VGG11 (128 -> 256, 256 -> 256) take the split-precision conv stage, every other
+    layer and every call that needs gradients stays exact.  Logits within 1e-4 of the exact model's (max-normalised); outside the context, and in a
+    training step inside it, the results are the exact path's bit for bit."""
+    from convkan_amd import ops
+    from convkan_amd.models import vggkan
+    torch.manual_seed(1)
+    m = vggkan(3, 10, arch="VGG11", kan_conv="KAN", dropout_linear=0.0).cuda().eval()
+    x = torch.randn(64, 3, 32, 32, device="cuda")
+    calls = []
+    orig = ops.kan_conv_fwd_split
+    ops.kan_conv_fwd_split = lambda *a, **k: (calls.append(a[1].shape), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            exact = m(x)
+            with ops.split_precision_inference():
+                split = m(x)
+                again = m(x)                                             # cut weights come from the cache
+            after = m(x)
+        assert [tuple(c) for c in calls] == [(64, 128, 8, 8), (64, 256, 8, 8)] * 2, calls
+        assert torch.equal(split, again) and torch.equal(exact, after)
+        err = float((split - exact).abs().max() / exact.abs().max())
+        print(f"[split inference] logits vs exact model: {err:.2e}")
+        assert 0.0 < err <= 1e-4, err
+        n = len(calls)
+        with ops.split_precision_inference():                             # with grad mode on (a training step) nothing leaves the exact path
+            m.train()
+            y1 = m(x)
+        y0 = m(x)
+        assert len(calls) == n and torch.equal(y0, y1)
+    finally:
+        ops.kan_conv_fwd_split = orig

@@ -83,3 +83,37 @@ def test_fused_pool_rejects_bad_windows(gpu_lib):
         layer(x, pool=(3, 4))                                # stride > kernel
     with pytest.raises(L.KanConvError):
         layer(x, pool=(9, 2))                                # window larger than the plane
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_pool_fuzz(seed, gpu_lib):
+    """Random (kernel, stride, plane, channel) draws of the fused pool against layer + max_pool2d: window classes ceil(k / s)^2 in {1, 4, 9, 16, 25}, planes with
+    trailing rows / columns no window covers, planes above and below the LDS / register-kernel limits."""
+    import random
+    import convkan_amd as K
+    rnd = random.Random(1000 + seed)
+    pk = rnd.randint(2, 5)
+    ps = rnd.randint(1, pk)
+    H, W = rnd.randint(pk + 1, 40), rnd.randint(pk + 1, 40)
+    C, O = rnd.choice([1, 3, 4]), rnd.choice([4, 8, 12])
+    kind = rnd.choice(["kan", "cheby"])
+    B = rnd.choice([1, 3, 5])
+    torch.manual_seed(seed)
+    layer = (K.KANConv2DLayer(C, O, 3, padding=1, base_activation=torch.nn.SiLU) if kind == "kan" else K.ChebyKANConv2DLayer(C, O, 3, padding=1, degree=3, affine=True)).cuda().train()
+    x = torch.randn(B, C, H, W, device="cuda")
+    res = []
+    for fused in (True, False):
+        layer.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi, pool=(pk, ps)) if fused else F.max_pool2d(layer(xi), pk, ps)
+        g = torch.cos(torch.arange(y.numel(), device="cuda", dtype=torch.float32) * 0.73).view_as(y)
+        y.backward(g)
+        torch.cuda.synchronize()
+        res.append((y.detach(), xi.grad, {n: q.grad.clone() for n, q in layer.named_parameters() if q.grad is not None}))
+    (yf, dxf, gf), (yu, dxu, gu) = res
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    tag = f"{kind} C{C} O{O} {H}x{W} B{B} pool {pk}/{ps}"
+    assert yf.shape == yu.shape, tag
+    assert rel(yf, yu) <= 2e-6 and rel(dxf, dxu) <= 2e-5, (tag, rel(yf, yu), rel(dxf, dxu))
+    for n in gu:
+        assert rel(gf[n], gu[n]) <= 2e-5, (tag, n, rel(gf[n], gu[n]))

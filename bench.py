@@ -354,19 +354,13 @@ def other_workload(name, device, steps, warmup):
 
 def split_precision_forward(device, iters: int = 20):
     """OPT-IN mode, reported apart from everything else (`dtype` f32 above is the exact path and stays the default and the headline): the split-precision
-    forward of the 256 -> 256 @ 8x8 layer (3 x bf16 pieces, six bf16 MFMA products per k-block; kanconv.h kan_conv_fwd_split) next to the exact kernel of the
-    same layer, same inputs; `max_diff_vs_exact` is max |z_split - z_exact| / max |z_exact| (tests/test_gpu_split.py holds the fp64 comparison)."""
+    forward (3 x bf16 pieces, six bf16 MFMA products per k-block; kanconv.h kan_conv_fwd_split) of the three KAN-VGG11 layers in its scope next to the exact
+    kernel of the same layer, same inputs; `max_diff_vs_exact` is max |z_split - z_exact| / max |z_exact| (tests/test_gpu_split.py holds the fp64 comparison).
+    The top-level figures are the 256 -> 256 @ 8x8 layer."""
     import torch
     try:
         import convkan_amd as K
         from convkan_amd import ops
-        torch.manual_seed(0)
-        layer = K.KANConv2DLayer(256, 256, 3, padding=1, base_activation=torch.nn.SiLU).to(device)      # KAN-VGG11's layer 4 (models/kan_vgg.py)
-        x = torch.randn(256, 256, 8, 8, device=device)
-        spec, wb, ws = layer.conv_spec(), layer.base_conv[0].weight.detach(), layer.spline_conv[0].weight.detach()
-        z_s, wc = ops.kan_conv_fwd_split(spec, x, wb, ws)
-        z_e = ops.kan_conv(spec, x, None, [wb], [ws])
-        diff = float((z_s - z_e).abs().max() / z_e.abs().max())
 
         def timed(fn):
             for _ in range(3):
@@ -377,12 +371,26 @@ def split_precision_forward(device, iters: int = 20):
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / iters
-        ms_s = timed(lambda: ops.kan_conv_fwd_split(spec, x, wb, ws, wc))
-        ms_e = timed(lambda: ops.kan_conv(spec, x, None, [wb], [ws]))
-        gf = 2.0 * 256 * 64 * 256 * 256 * 81 / 1e9
-        return {"workload": "conv stage forward of KANConv2DLayer 256->256 @ 8x8, bs 256 (opt-in split-precision mode vs the exact fp32 kernel incl. its slab sum)",
-                "split_ms": round(ms_s, 4), "exact_ms": round(ms_e, 4), "split_tflops_fp32_equivalent": round(gf / ms_s, 1), "exact_tflops": round(gf / ms_e, 1),
-                "speedup": round(ms_e / ms_s, 2), "max_diff_vs_exact": diff, "default": False}
+        layers = []
+        for C_, O_, hw in ((256, 256, 8), (128, 256, 8), (64, 128, 16)):
+            torch.manual_seed(0)
+            layer = K.KANConv2DLayer(C_, O_, 3, padding=1, base_activation=torch.nn.SiLU).to(device)      # as models/kan_vgg.py builds it
+            x = torch.randn(256, C_, hw, hw, device=device)
+            spec, wb, ws = layer.conv_spec(), layer.base_conv[0].weight.detach(), layer.spline_conv[0].weight.detach()
+            z_s, wc = ops.kan_conv_fwd_split(spec, x, wb, ws)
+            z_e = ops.kan_conv(spec, x, None, [wb], [ws])
+            diff = float((z_s - z_e).abs().max() / z_e.abs().max())
+            ms_s = timed(lambda: ops.kan_conv_fwd_split(spec, x, wb, ws, wc))
+            ms_e = timed(lambda: ops.kan_conv(spec, x, None, [wb], [ws]))
+            gf = 2.0 * 256 * hw * hw * O_ * C_ * 81 / 1e9
+            layers.append({"layer": f"{C_}->{O_} @ {hw}x{hw}, bs 256", "split_ms": round(ms_s, 4), "exact_ms": round(ms_e, 4),
+                           "split_tflops_fp32_equivalent": round(gf / ms_s, 1), "exact_tflops": round(gf / ms_e, 1), "speedup": round(ms_e / ms_s, 2),
+                           "max_diff_vs_exact": diff})
+            del layer, x, z_s, z_e, wc
+        top = dict(layers[0])
+        top.pop("layer")
+        return dict({"workload": "conv stage forward of KANConv2DLayer 256->256 @ 8x8, bs 256 (opt-in split-precision mode vs the exact fp32 kernel incl. its slab sum)"},
+                    **top, default=False, layers=layers)
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 

@@ -3,11 +3,11 @@
 //
 // Every fp32 operand (expanded plane value, weight) is cut into three bf16 pieces hi + mid + lo (24 mantissa bits); each 16-deep k-block runs six
 // v_mfma_f32_32x32x16_bf16 products (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi) into the fp32 accumulator.  Scope of this first kernel: the default
-// B-spline spec (grid 5, order 3, SiLU base branch: P = 9 planes) on 8x8 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even batch --
-// KAN-VGG11's 128 -> 256 and 256 -> 256 layers.  Replaces, for such a layer, kan_layers.py:199-200, 203-239 (as kan_conv_fwd does).
+// B-spline spec (grid 5, order 3, SiLU base branch: P = 9 planes) on 8x8 or 16x16 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0 (even
+// batch on 8x8) -- KAN-VGG11's 64 -> 128 @ 16x16, 128 -> 256 and 256 -> 256 @ 8x8 layers.  Replaces, for such a layer, kan_layers.py:199-200, 203-239 (as kan_conv_fwd does).
 //
 // Kernel design (k_split_fwd), following the halo forward of the library:
-//   tile    128 outputs x 128 pixels (two whole 8x8 images) per workgroup, one workgroup per CU at the VGG shapes; 512 threads = 4 MFMA waves (wave tile
+//   tile    128 outputs x 128 pixels (two whole 8x8 images, or eight rows of one 16x16 image) per workgroup, one workgroup per CU at the VGG shapes; 512 threads = 4 MFMA waves (wave tile
 //           64 x 64, 2 x 2 blocks of 32 x 32) + 4 PRODUCER waves, one of each per SIMD;
 //   B side  per group of 8 input channels the producers expand the 2 x 64 input values once (SiLU + 8 B-spline planes, fp32 vector ALU), cut each
 //           plane into 3 bf16 pieces (v_cvt_pk_bf16_f32 on channel pairs) and write a zero-bordered halo tile per image into LDS, plane-major inside a
@@ -46,13 +46,20 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 #define BAR_PLAIN() asm volatile("s_barrier" ::: "memory")
 #define BAR_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-constexpr int HW = 64, NP = 9, CG = 8, NGRP = 84, NSTEP = NGRP / 2;
-constexpr int CELLC = 9, ROWC = 88, IMGC = 10 * ROWC;                // chunks (16 B) per cell / halo row / image
-constexpr int SPLITB = (2 * IMGC + 2) * 16, HALOB = 3 * SPLITB;      // bytes per piece (two images + the overhang of the last border cell), per halo tile
+constexpr int NP = 9, CG = 8, NGRP = 84, NSTEP = NGRP / 2;
+constexpr int CELLC = 9;                                             // chunks (16 B) per cell
+// Pixel tile = 128 pixels: two whole 8x8 images (PW = 8: 2 x 10 halo rows of 10 cells) or eight rows of one 16x16 image (PW = 16: 10 halo rows of 18
+// cells, the outer two real data or image border depending on the half).  Row pitch in chunks: the right border cell of a row overlaps the left border
+// cell of the next (both zero, never written); 88 = 8 mod 16 for 8-pixel rows and 160 = 0 mod 16 for 16-pixel rows make the four lane groups of a
+// ds_read_b128 (two / one image rows of a 32-pixel block each) cover all sixteen 16-byte slots.
+template <int PW> struct SplitGeo {
+    static constexpr int ROWC = PW == 8 ? 88 : 160, ROWS = PW == 8 ? 20 : 10, HWP = PW * PW;
+    static constexpr int SPLITB = (ROWS * ROWC + 2) * 16, HALOB = 3 * SPLITB;      // bytes per piece (+ the overhang of the last border cell), per halo tile
+};
 constexpr int WSLOT = 3 * 2 * 128 * 16, NBUF = 6;                    // one step of one 128-output tile in LDS
-constexpr int LDS_BYTES = HALOB + NBUF * WSLOT + NGRP * 4 + 64;
+template <int PW> constexpr int lds_bytes() { return SplitGeo<PW>::HALOB + NBUF * WSLOT + NGRP * 4 + 64; }
 
-__device__ constexpr int off_of(int gi) { return gi < 81 ? (((gi / 9) / 3 - 1) * ROWC + ((gi / 9) % 3 - 1) * CELLC + gi % 9) * 16 : 0; }
+template <int ROWC> __device__ constexpr int off_of(int gi) { return gi < 81 ? (((gi / 9) / 3 - 1) * ROWC + ((gi / 9) % 3 - 1) * CELLC + gi % 9) * 16 : 0; }
 __device__ inline int split_mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 #define mfma_row split_mfma_row
 
@@ -85,8 +92,10 @@ __global__ void k_cut_weights(const float* __restrict__ wb, const float* __restr
 }
 
 // ---- the forward
+template <int PW>
 __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ x, const __bf16* __restrict__ wc, float* __restrict__ z, DevBasis bs, int NC, int NO, int o_tiles) {
     const int NCG = NC / CG, TOTAL_STEPS = NCG * NSTEP, WSTEP_G = 3 * 2 * NO * 16;        // channel groups, 16-deep steps, bytes of one step of the cut weights
+    constexpr int ROWC = SplitGeo<PW>::ROWC, SPLITB = SplitGeo<PW>::SPLITB, HALOB = SplitGeo<PW>::HALOB, HW = SplitGeo<PW>::HWP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sH = smem;
     unsigned char* sW = smem + HALOB;
@@ -94,7 +103,8 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
     float* sTab = (float*)(sOff + NGRP);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w_o = wave & 1, w_p = wave >> 1, kh = lane >> 5, m = lane & 31;
-    const int ot = blockIdx.x % o_tiles, b0 = (blockIdx.x / o_tiles) * 2;
+    const int ot = blockIdx.x % o_tiles, ptile = blockIdx.x / o_tiles;
+    const int b0 = PW == 8 ? ptile * 2 : ptile >> 1, half_img = PW == 8 ? 0 : (ptile & 1);      // PW = 16: image b0, rows [8 half_img, 8 half_img + 8)
 
     for (int i = tid; i < HALOB / 16; i += 512) ((uint4*)sH)[i] = uint4{0u, 0u, 0u, 0u};
     if (tid < NGRP) {
@@ -121,8 +131,9 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
     unsigned bBase[2];
 #pragma unroll
     for (int bj = 0; bj < 2; ++bj) {
-        const int lp = bj * 32 + m, r = lp >> 3, c = lp & 7;
-        bBase[bj] = (unsigned)(((w_p * 10 + r + 1) * ROWC + (c + 1) * CELLC) * 16);
+        const int lp = bj * 32 + m;
+        const int hrow = PW == 8 ? w_p * 10 + (lp >> 3) + 1 : w_p * 4 + (lp >> 4) + 1, c = PW == 8 ? (lp & 7) : (lp & 15);      // halo row, column
+        bBase[bj] = (unsigned)((hrow * ROWC + (c + 1) * CELLC) * 16);
     }
     const unsigned aLane = (unsigned)(HALOB + (kh * 128 + w_o * 64 + m) * 16);
 
@@ -136,8 +147,13 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
 
     // expansion: thread = (pixel q of the 128, half hh of the channel group)
     const int q = tid & 127, hh = (tid >> 7) & 1, qi = q >> 6, lp = q & 63;
-    const unsigned cellB = (unsigned)(((qi * 10 + (lp >> 3) + 1) * ROWC + ((lp & 7) + 1) * CELLC) * 16 + hh * 8);
-    const float* xq = x + ((size_t)(b0 + qi) * NC + hh * 4) * HW + lp;
+    const unsigned cellB = PW == 8 ? (unsigned)(((qi * 10 + (lp >> 3) + 1) * ROWC + ((lp & 7) + 1) * CELLC) * 16 + hh * 8)
+                                   : (unsigned)((((q >> 4) + 1) * ROWC + ((q & 15) + 1) * CELLC) * 16 + hh * 8);
+    const float* xq = PW == 8 ? x + ((size_t)(b0 + qi) * NC + hh * 4) * HW + lp : x + ((size_t)b0 * NC + hh * 4) * HW + half_img * 128 + q;
+    // PW = 16: the ninth real row of the tile (image row 8 below the upper half, row 7 above the lower half) -- 16 pixels x 2 channel halves, lanes q < 16
+    const bool extra = PW == 16 && q < 16;
+    const unsigned cellX = (unsigned)(((half_img ? 0 : 9) * ROWC + (q + 1) * CELLC) * 16 + hh * 8);
+    const float* xqx = x + ((size_t)b0 * NC + hh * 4) * HW + (half_img ? 7 : 8) * 16 + (q & 15);
 
     // PRODUCER waves (4 .. 7, one per SIMD next to an MFMA wave): the hardware issues their vector work in the MFMA waves' gaps.  They compute the
     // next channel group's pieces into registers while the current group is contracted, and write them once the halo tile is free.
@@ -152,11 +168,11 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
         m = pk(r0, r1);
         l = pk(r0 - __builtin_bit_cast(float, m << 16), r1 - __builtin_bit_cast(float, m & 0xffff0000u));
     };
-    auto compute = [&](int cg, Pieces& pc) {
+    auto compute = [&](int cg, Pieces& pc, const float* xsrc) {
         float v[4][NP];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float xv = xq[(size_t)(cg * CG + j) * HW];
+            const float xv = xsrc[(size_t)(cg * CG + j) * HW];
             v[j][0] = xv * kan_rcp(1.0f + kan_exp2k(xv, -1.44269504088896340736f));      // SiLU through hardware exp2 / rcp, as the library's fast specs
             int j0 = 0; float N[4];
             const bool ok = bspline_uniform<false>(3, xv, sTab, 12, bs.inv_h, j0, N);
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
             split_pair(v[2][p], v[3][p], pc.h[p].y, pc.m[p].y, pc.l[p].y);
         }
     };
-    auto write = [&](const Pieces& pc) {
+    auto write = [&](const Pieces& pc, unsigned cellB) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             *(uint2*)(sH + cellB + p * 16) = pc.h[p];
@@ -189,17 +205,18 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
     if (tid >= 256) {
         // producers also stream the weights (the MFMA waves issue no vector-memory instruction at all in the main loop): steps t+6, t+7 go out at the
         // barrier of pair t, and that barrier is entered only when all but the six newest copies (steps t+4, t+5) have landed
-        Pieces pc;
+        Pieces pc, px;                                     // px: the extra halo row of a 16x16 tile (lanes q < 16)
         for (int i = 0; i < NBUF; ++i) issue2(i, i);
         __syncthreads();                                   // B1: zero fill, tables
-        compute(0, pc); write(pc);
+        compute(0, pc, xq); write(pc, cellB);
+        if (extra) { compute(0, px, xqx); write(px, cellX); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // B2
         int t = 0;
 #pragma unroll 1
         for (int cg = 0; cg < NCG; ++cg) {
             const bool more = cg + 1 < NCG;
-            if (more) compute(cg + 1, pc);
+            if (more) { compute(cg + 1, pc, xq); if (extra) compute(cg + 1, px, xqx); }
 #pragma unroll
             for (int pr = 0; pr < NSTEP / 2; ++pr) {
                 if (t + 4 < TOTAL_STEPS) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
                 if (t + 6 < TOTAL_STEPS) { issue2(t + 6, 2 * pr); issue2(t + 7, 2 * pr + 1); }
                 t += 2;
             }
-            if (more) { write(pc); BAR_LDS(); }
+            if (more) { write(pc, cellB); if (extra) write(px, cellX); BAR_LDS(); }
         }
         return;
     }
@@ -219,7 +236,7 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
                      "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1]), "+v"(f.b[2][0]), "+v"(f.b[2][1])
     auto loadF = [&](Frag& f, int tt, int st) {
         const unsigned ao = aLane + (unsigned)((tt % NBUF) * WSLOT);
-        const unsigned off = (unsigned)(kh ? off_of(2 * st + 1) : off_of(2 * st));
+        const unsigned off = (unsigned)(kh ? off_of<ROWC>(2 * st + 1) : off_of<ROWC>(2 * st));
         const unsigned p0 = bBase[0] + off, p1 = bBase[1] + off, q0 = p0 + 2 * SPLITB, q1 = p1 + 2 * SPLITB;
         DSR(f.a[0][0], ao, 0);    DSR(f.a[0][1], ao, 512);
         DSR(f.b[0][0], p0, 0);    DSR(f.b[0][1], p1, 0);
@@ -236,7 +253,7 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
         unsigned ao = 0, p0 = 0, p1 = 0, q0 = 0, q1 = 0;
         if (load_next) {
             ao = aLane + (unsigned)((tt_next % NBUF) * WSLOT);
-            const unsigned off = (unsigned)(kh ? off_of(2 * st_next + 1) : off_of(2 * st_next));
+            const unsigned off = (unsigned)(kh ? off_of<ROWC>(2 * st_next + 1) : off_of<ROWC>(2 * st_next));
             p0 = bBase[0] + off; p1 = bBase[1] + off; q0 = p0 + 2 * SPLITB; q1 = p1 + 2 * SPLITB;
         }
         int gap = 0;
@@ -287,7 +304,8 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
         }
     }
     // ---- store: column (lane) = pixel
-    float* zi = z + ((size_t)(b0 + w_p) * NO + ot * 128 + w_o * 64) * HW;
+    float* zi = PW == 8 ? z + ((size_t)(b0 + w_p) * NO + ot * 128 + w_o * 64) * HW
+                        : z + ((size_t)b0 * NO + ot * 128 + w_o * 64) * HW + half_img * 128 + w_p * 64;      // (16-pixel rows: a block's 32 pixels are contiguous)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -300,10 +318,10 @@ __global__ __launch_bounds__(512, 1) void k_split_fwd(const float* __restrict__ 
 const char* split_reject(const KanGeom* g, const KanBasis* b) {
     if (!g || !b) return "null geometry / basis";
     if (b->kind != KAN_BASIS_BSPLINE || b->n_basis != 8 || b->order != 3 || b->act != KAN_ACT_SILU) return "split-precision forward: default B-spline spec only (grid 5, order 3, SiLU)";
-    if (g->H != 8 || g->W != 8 || g->Ho != 8 || g->Wo != 8 || g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->ph != 1 || g->pw != 1 || g->dh != 1 || g->dw != 1)
-        return "split-precision forward: 8x8 planes, 3x3 / stride 1 / pad 1 only";
-    if (g->groups > 1 || g->C % CG || g->O % 128 || g->B % 2 || g->C < CG) return "split-precision forward: one group, C % 8 == 0, O % 128 == 0, even batch";
-    if (g->x_bstride != (long long)g->C * HW || g->y_bstride != (long long)g->O * HW) return "split-precision forward: dense NCHW tensors";
+    if (!((g->H == 8 && g->W == 8) || (g->H == 16 && g->W == 16)) || g->Ho != g->H || g->Wo != g->W || g->kh != 3 || g->kw != 3 || g->sh != 1 || g->sw != 1 || g->ph != 1 || g->pw != 1 || g->dh != 1 || g->dw != 1)
+        return "split-precision forward: 8x8 or 16x16 planes, 3x3 / stride 1 / pad 1 only";
+    if (g->groups > 1 || g->C % CG || g->O % 128 || (g->H == 8 && g->B % 2) || g->C < CG) return "split-precision forward: one group, C % 8 == 0, O % 128 == 0, even batch on 8x8 planes";
+    if (g->x_bstride != (long long)g->C * g->H * g->W || g->y_bstride != (long long)g->O * g->H * g->W) return "split-precision forward: dense NCHW tensors";
     if ((long long)(g->C / CG) * NSTEP * 3 * 2 * g->O * 16 >= (1ll << 31)) return "split-precision forward: cut weights must stay under 2 GiB";
     return nullptr;
 }
@@ -334,13 +352,17 @@ int kan_conv_fwd_split(const float* x, const void* wc, float* z, const KanGeom* 
     if (!x || !wc || !z) return kan_fail_msg("kan_conv_fwd_split: null pointer%s", "");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)k_split_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)k_split_fwd<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<8>()) != hipSuccess ||
+            hipFuncSetAttribute((const void*)k_split_fwd<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes<16>()) != hipSuccess)
             return kan_fail_msg("kan_conv_fwd_split: cannot reserve %s of LDS", "158 KB");
         attr_set = true;
     }
     const DevBasis db = dev_basis(b);
     const int o_tiles = g->O / 128;
-    hipLaunchKernelGGL(k_split_fwd, dim3((unsigned)((g->B / 2) * o_tiles)), dim3(512), LDS_BYTES, (hipStream_t)stream, x, (const __bf16*)wc, z, db, g->C, g->O, o_tiles);
+    if (g->H == 8)
+        hipLaunchKernelGGL(k_split_fwd<8>, dim3((unsigned)((g->B / 2) * o_tiles)), dim3(512), lds_bytes<8>(), (hipStream_t)stream, x, (const __bf16*)wc, z, db, g->C, g->O, o_tiles);
+    else
+        hipLaunchKernelGGL(k_split_fwd<16>, dim3((unsigned)(g->B * 2 * o_tiles)), dim3(512), lds_bytes<16>(), (hipStream_t)stream, x, (const __bf16*)wc, z, db, g->C, g->O, o_tiles);
     return hipGetLastError() == hipSuccess ? 0 : kan_fail_msg("kan_conv_fwd_split: launch failed%s", "");
 }
 

@@ -255,8 +255,8 @@ _SPLIT_CACHE: "OrderedDict" = OrderedDict()             # (weight addresses) -> 
 @contextlib.contextmanager
 def split_precision_inference():
     """OPT-IN, inference only: inside, a fused conv + InstanceNorm + PReLU stage whose inputs need no gradient (torch.no_grad() / eval serving) and whose
-    geometry is in scope of `kan_conv_fwd_split` (default B-spline spec on 8x8 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even
-    batch) runs its conv stage in split precision (3 x bf16 pieces, six bf16 MFMA products; ~4e-6 of the largest pre-norm value from the exact result, 1.7x
+    geometry is in scope of `kan_conv_fwd_split` (default B-spline spec on 8x8 / 16x16 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0,
+    even batch on 8x8) runs its conv stage in split precision (3 x bf16 pieces, six bf16 MFMA products; ~4e-6 of the largest pre-norm value from the exact result, 1.7x
     faster).  Everything else -- every other layer, and every training step -- stays on exact fp32 MFMA.  Never on by default."""
     global _SPLIT_INFERENCE
     prev, _SPLIT_INFERENCE = _SPLIT_INFERENCE, True
@@ -916,8 +916,8 @@ def kan_conv_in_prelu(spec: ConvSpec, x: torch.Tensor, w_base: Sequence[torch.Te
 
 def kan_conv_fwd_split(spec: ConvSpec, x: torch.Tensor, w_base: torch.Tensor, w_basis: torch.Tensor, wc: Optional[torch.Tensor] = None):
     """OPT-IN split-precision conv stage (forward only, no autograd; kanconv.h `kan_conv_fwd_split`): the fp32 result of `kan_conv` to ~4e-6 of its largest
-    element, through 3 x bf16 pieces and six bf16 MFMA products per k-block.  Never used by the layers; scope: default B-spline spec on 8x8 planes, 3x3 /
-    stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even batch (raises KanConvError otherwise).  Returns (z, wc): pass `wc` back while the
+    element, through 3 x bf16 pieces and six bf16 MFMA products per k-block.  Never used by the layers; scope: default B-spline spec on 8x8 or 16x16 planes, 3x3 /
+    stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even batch on 8x8 (raises KanConvError otherwise).  Returns (z, wc): pass `wc` back while the
     weights are unchanged to skip the cut (0.05 ms at 256 -> 256)."""
     lib = L.load()
     x, w_base, w_basis = _require(x, "x"), _require(w_base, "w_base"), _require(w_basis, "w_basis")
@@ -925,7 +925,7 @@ def kan_conv_fwd_split(spec: ConvSpec, x: torch.Tensor, w_base: torch.Tensor, w_
     Ot = w_basis.shape[0]
     geom, basis, _ = _plan_cached(spec, B, Ct, H, W, Ot, Ct, Ot)
     if not lib.kan_split_supported(C.byref(geom), C.byref(basis)):
-        raise L.KanConvError("split-precision forward: default B-spline spec (grid 5, order 3, SiLU base branch), 8x8 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, "
+        raise L.KanConvError("split-precision forward: default B-spline spec (grid 5, order 3, SiLU base branch), 8x8 or 16x16 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, "
                              "even batch only")
     with torch.cuda.device(x.device):
         if wc is None:

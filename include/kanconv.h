@@ -267,12 +267,12 @@ int kan_instnorm_prelu_poolk_bwd(const float* dy_pooled, const unsigned char* po
 /* OPT-IN split-precision forward: NOT reached from kan_conv_fwd, never the default.  Every fp32 operand is cut into three bf16
  * pieces (hi + mid + lo = 24 mantissa bits) and six bf16 MFMA products per 16-deep block are accumulated in fp32: the fp32 result to ~4e-6 of its
  * largest element at K = 20 736 (one fp32 accumulation chain; the exact path sits at ~1e-6), at ~1.7x the speed of the exact fp32 MFMA kernel.
- * Scope: the default B-spline spec (n_basis 8, order 3, SiLU) on 8x8 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even B, dense NCHW
- * -- KAN-VGG11's 128 -> 256 and 256 -> 256 layers.  Computes what kan_conv_fwd computes for such a layer (kan_layers.py:199-200, 203-239) into ONE slab.
+ * Scope: the default B-spline spec (n_basis 8, order 3, SiLU) on 8x8 or 16x16 planes, 3x3 / stride 1 / pad 1, one group, C % 8 == 0, O % 128 == 0, even B on 8x8
+ * planes, dense NCHW -- KAN-VGG11's 64 -> 128 @ 16x16, 128 -> 256 and 256 -> 256 @ 8x8 layers.  Computes what kan_conv_fwd computes for such a layer (kan_layers.py:199-200, 203-239) into ONE slab.
  *   kan_split_supported      1 if (geom, basis) is in scope
  *   kan_split_weight_bytes   size of the cut-weight buffer `wc` (0 if out of scope)
  *   kan_split_pack_weights   reference-layout weights (as kan_pack_weights takes them) -> wc; once per weight update
- *   kan_conv_fwd_split       z[B][O][8][8] = the conv stage */
+ *   kan_conv_fwd_split       z[B][O][H][W] = the conv stage */
 int kan_split_supported(const KanGeom* geom, const KanBasis* basis);
 long long kan_split_weight_bytes(const KanGeom* geom, const KanBasis* basis);
 int kan_split_pack_weights(const float* w_base, const float* w_basis, void* wc, const KanGeom* geom, const KanBasis* basis, void* stream);

@@ -396,3 +396,24 @@ def test_alexnet_plain_pool_detection():
     for bad in (nn.MaxPool2d(3, 2, padding=1), nn.MaxPool2d(3, 2, ceil_mode=True), nn.MaxPool2d((3, 2), 2), nn.MaxPool2d(3, 2, dilation=2),
                 nn.MaxPool2d(2, 3), nn.MaxPool2d(3, 2, return_indices=True)):
         assert _plain_pool(bad) is None
+
+
+def test_opt_in_switches_restore_their_flags_and_pool_arguments_are_checked():
+    """ops.always_pack / ops.split_precision_inference are context managers that leave no state behind (also on an exception); the fused-pool argument
+    takes True, False or a (kernel, stride) pair with 2 <= kernel <= 15, 1 <= stride <= kernel."""
+    from convkan_amd import ops
+    assert ops._ALWAYS_PACK is False and ops._SPLIT_INFERENCE is False
+    with ops.always_pack():
+        assert ops._ALWAYS_PACK is True
+        with ops.split_precision_inference():
+            assert ops._SPLIT_INFERENCE is True
+        assert ops._SPLIT_INFERENCE is False
+    assert ops._ALWAYS_PACK is False
+    with pytest.raises(RuntimeError):
+        with ops.split_precision_inference():
+            raise RuntimeError("x")
+    assert ops._SPLIT_INFERENCE is False
+    assert ops._norm_pool(False) is False and ops._norm_pool(True) is True and ops._norm_pool((3, 2)) == (3, 2) and ops._norm_pool([2, 2]) == (2, 2)
+    for bad in ((1, 1), (3, 4), (16, 2), (3, 0)):
+        with pytest.raises(L.KanConvError):
+            ops._norm_pool(bad)

@@ -1777,7 +1777,7 @@ __global__ __launch_bounds__(256, 4) void k_conv_fwd_pmdma(
 // dealt in order of their linear id as slots free up, so the host sorts the (tap, split) classes by DECREASING step count (longest first: greedy
 // list scheduling) and the kernel looks its (tile, split) up from a flat id; empty splits (they still write their zero slab) come last.
 constexpr int PM_ORDER_MAX = 72;
-struct PmOrder { int n, tiles_r_per_tap; unsigned char tap[PM_ORDER_MAX], z[PM_ORDER_MAX]; int first[PM_ORDER_MAX + 1]; };   // n == 0: plain 3-D grid
+struct PmOrder { int n, tiles_r_per_tap, xcd; unsigned char tap[PM_ORDER_MAX], z[PM_ORDER_MAX]; int first[PM_ORDER_MAX + 1]; };   // n == 0: plain 3-D grid
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
@@ -1795,8 +1795,14 @@ __global__ __launch_bounds__(256, 4) void k_conv_bwd_weight_pmdma(
         const int lin = (int)blockIdx.x;
         int e = 0;
         while (e + 1 < ord.n && lin >= ord.first[e + 1]) ++e;
-        const int rel = lin - ord.first[e], y = rel / ord.tiles_r_per_tap;
-        blk.x = (int)ord.tap[e] * ord.tiles_r_per_tap + (rel - y * ord.tiles_r_per_tap); blk.y = y; blk.z = (int)ord.z[e];
+        // Inside a class: workgroup ids go round-robin over the 8 XCDs, each with its own L2, and a (row tile, output tile) workgroup reads 128 rows of the
+        // expanded operand and 128 rows of dz over its pixel range.  XCD k takes a CONTIGUOUS range of the class, ordered output tile fastest, so that the
+        // workgroups sharing a row tile (its 4 output tiles) and those sharing an output tile run side by side behind ONE L2: each operand line is
+        // fetched once per XCD for ~4 consumers (was: row-tile neighbours on different XCDs, the expanded operand re-fetched by every output tile).
+        const int rel0 = lin - ord.first[e], per = ord.first[e + 1] - ord.first[e], ny = per / ord.tiles_r_per_tap;
+        const int rel = ((per & 7) == 0 && (ord.first[e] & 7) == 0 && ord.xcd) ? (rel0 & 7) * (per >> 3) + (rel0 >> 3) : rel0;
+        const int xr = rel / ny, y = rel - xr * ny;
+        blk.x = (int)ord.tap[e] * ord.tiles_r_per_tap + xr; blk.y = y; blk.z = (int)ord.z[e];
     }
     const int grp = blk.y / tiles_o;
     const int k0 = blk.x * TR, o_tile0 = (blk.y - grp * tiles_o) * TO;
@@ -3621,7 +3627,7 @@ int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* d
     dim3 grid(c.tiles_r, c.tiles_o * ngroups(g), pl.bwd_weight_splits);
     // longest-first dispatch order over the (tap, split) classes (PmOrder): live steps of a tap = live positions x 16-image chunks, cut into
     // min(splits, ceil(live / target)) ranges exactly as the kernel cuts them
-    PmOrder ord; ord.n = 0;
+    PmOrder ord; ord.n = 0; ord.xcd = 0;
     const int T = g->kh * g->kw, S = pl.bwd_weight_splits, trpt = (g->C * pl.P) / 128;
     if (!tuning_off("KAN_PM_LPT") && T * S <= PM_ORDER_MAX && T <= 255 && S <= 255 && trpt * T == c.tiles_r) {
         int steps[PM_ORDER_MAX], idx[PM_ORDER_MAX], n = 0;
@@ -3641,7 +3647,7 @@ int kan_conv_bwd_weight_expanded(const float* dz_pm, const float* e_pm, float* d
             idx[j] = v;
         }
         const int per_entry = trpt * c.tiles_o * ngroups(g);
-        ord.n = n; ord.tiles_r_per_tap = trpt;
+        ord.n = n; ord.tiles_r_per_tap = trpt; ord.xcd = tuning_off("KAN_PM_XCD") ? 0 : 1;
         for (int i = 0; i < n; ++i) { ord.tap[i] = tp[idx[i]]; ord.z[i] = zz[idx[i]]; ord.first[i] = i * per_entry; }
         ord.first[n] = n * per_entry;
         grid = dim3((unsigned)(n * per_entry), 1, 1);

@@ -395,6 +395,39 @@ def split_precision_forward(device, iters: int = 20):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def inference_modes(device, iters: int = 30):
+    """KAN-VGG11 forward only (eval, torch.no_grad, bs 256): the exact path, and the OPT-IN `ops.split_precision_inference()` switch under which the three
+    layers in scope of kan_conv_fwd_split run their conv stage in split precision (`logits_max_diff_vs_exact` = max |difference| / max |exact logits|)."""
+    import torch
+    try:
+        from convkan_amd import ops
+        model = build_model(device, "kan_vgg11").eval()
+        x = torch.randn(256, 3, 32, 32, device=device, generator=torch.Generator(device=device).manual_seed(4))
+
+        def timed():
+            for _ in range(5):
+                y = model(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(); e0.record()
+            for _ in range(iters):
+                y = model(x)
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters, y
+        with torch.no_grad():
+            ms_e, y_e = timed()
+            with ops.split_precision_inference():
+                ms_s, y_s = timed()
+        out = {"workload": "KAN-VGG11 forward only (eval, no_grad), 3x32x32, bs 256",
+               "exact": {"ms_per_batch": round(ms_e, 3), "images_per_sec": round(256 / ms_e * 1e3, 1)},
+               "split_precision_opt_in": {"ms_per_batch": round(ms_s, 3), "images_per_sec": round(256 / ms_s * 1e3, 1),
+                                          "logits_max_diff_vs_exact": float((y_s - y_e).abs().max() / y_e.abs().max()), "default": False}}
+        del model, x
+        torch.cuda.empty_cache()
+        return out
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 # --------------------------------------------------------------------------------------------------- multi-rank launch
 def kfd_gpu_count():
     """GPUs of this node as the kernel driver lists them (KFD topology nodes with SIMDs; CPUs have simd_count 0), cut to the
@@ -560,7 +593,8 @@ def main():
             torch.cuda.empty_cache()
             out["other_workloads"] = {"fastkan_layer": other_workload("fastkan_layer", device, 30, 10),
                                       "cheby_alexnet": other_workload("cheby_alexnet", device, 10, 3),
-                                      "split_precision_forward": split_precision_forward(device)}
+                                      "split_precision_forward": split_precision_forward(device),
+                                      "kan_vgg11_inference": inference_modes(device)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "kan_vgg11":
             out["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_iters, args.cpu_warmup)
             out["cpu_baseline"]["gpu_over_cpu"] = round(ips / out["cpu_baseline"]["value"], 1)
